@@ -1,0 +1,159 @@
+/*
+ * tinyntt.h — C ABI of libtinyntt.so: batched negacyclic polynomial
+ * multiplication in Z_q[x]/(x^n+1) on AMD MI355X (gfx950), bit-exact against
+ * orhosko/tiny-ntt's golden model.
+ *
+ * The reference has no FFI layer for this path: its boundary is the Python
+ * signature `nwc_poly_mult(a, b, psi_2n) -> c` (new_reference/cg_ntt.py:78),
+ * its 8-butterfly twin (new_reference/cg_ntt_8butterfly.py:107), the transforms
+ * `cg_ntt` / `cg_intt` (cg_ntt.py:29,68) and the C++ benchmark entry
+ * `negacyclic_mul_ntt(a, b, out)` (software_benchmark/benchmark_ntt_60bit.cpp:148,
+ * benchmark_ntt.cpp:194).  Each entry point below names the reference interface
+ * it replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - Plain C: opaque plan handle, raw pointers, sizes; no C++/torch types.
+ *   - Coefficients: row-major [batch][n], little-endian, uint32_t when q < 2^31,
+ *     uint64_t otherwise (tn_plan_elem_bytes tells which).  Natural coefficient
+ *     order in and out.  Outputs are canonical residues in [0, q)
+ *     (cg_ntt.py:58-59 — Python's % is non-negative).
+ *   - Inputs need not be reduced: any word value is taken mod q, as the
+ *     reference's `%` does (cg_ntt.py:82-83).
+ *   - *_dev entry points take DEVICE pointers (hipMalloc / torch tensors) and a
+ *     hipStream_t passed as void* (NULL = the plan's own stream); they enqueue
+ *     and return.  *_host entry points take host pointers, copy in, run, copy
+ *     out and synchronise.
+ *   - a, b are read-only; c must not alias a or b.
+ *   - Every function returns a tn_status; nothing throws or aborts across the
+ *     ABI.  tn_last_error() gives the message for the calling thread.
+ *   - A plan is immutable after creation; calls on one plan serialise on the
+ *     stream they are given; distinct plans/devices may be used from distinct
+ *     host threads.
+ */
+#ifndef TINYNTT_H
+#define TINYNTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_VERSION 100 /* 0.1.0 */
+
+typedef enum tn_status {
+  TN_OK = 0,
+  TN_EBADLEN = 1,   /* n not a supported power of two / wrong length  (ValueError at cg_ntt.py:36-37,:69-70,:79-80) */
+  TN_EBADPARAM = 2, /* q even / out of range, psi^n != -1 mod q        (static_asserts at benchmark_ntt_60bit.cpp:58-59) */
+  TN_ENODEVICE = 3, /* no usable HIP device: the library never falls back to a CPU path */
+  TN_EHIP = 4,      /* a HIP runtime call failed */
+  TN_ENOMEM = 5,
+  TN_EINVAL = 6,    /* NULL pointer, aliasing, unknown variant */
+  TN_EUNSUPPORTED = 7
+} tn_status;
+
+/* Kernel schedule selector.  All variants return identical bits. */
+typedef enum tn_variant {
+  TN_VARIANT_AUTO = 0,  /* fastest available: FUSED when the plan supports it, else CG */
+  TN_VARIANT_FUSED = 1, /* register/LDS-tiled merged-twiddle kernel (the throughput path) */
+  TN_VARIANT_CG = 2,    /* constant-geometry stage sweep in LDS: the dataflow of cg_ntt.py:49-64 */
+  TN_VARIANT_CG8 = 3,   /* same, butterflies issued 8 per lane-step: cg_ntt_8butterfly.py:61-89 */
+  TN_VARIANT_CG8_PADDED = 4 /* CG8 with the padded (bank-conflict-free) LDS image; for the rocprof sweep */
+} tn_variant;
+
+typedef struct tn_plan tn_plan;
+
+/* Plan flags */
+#define TN_PLAN_DEFAULT 0u
+#define TN_PLAN_FORCE_CANONICAL 1u /* disable lazy reduction in the FUSED kernel (debug / generic-modulus path) */
+
+/*
+ * Create a plan for (n, q, psi) on HIP device `device`.
+ * Replaces: module constants N, Q (cg_ntt.py:5-6) + the psi_2n argument of
+ * nwc_poly_mult (:78); BENCH_N/BENCH_Q/BENCH_PSI (software_benchmark/CMakeLists.txt:5-7)
+ * and the constexpr tables PsiPowers/OmegaPowers/... (benchmark_ntt_60bit.cpp:43-64).
+ * Validates n = 2^m (4 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q).
+ */
+tn_status tn_plan_create(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags);
+tn_status tn_plan_destroy(tn_plan *plan);
+
+uint32_t tn_plan_n(const tn_plan *plan);
+uint64_t tn_plan_q(const tn_plan *plan);
+uint64_t tn_plan_psi(const tn_plan *plan);
+uint64_t tn_plan_omega(const tn_plan *plan);      /* psi^2: the omega_n that nwc_poly_mult passes to cg_ntt (cg_ntt.py:85) */
+uint32_t tn_plan_elem_bytes(const tn_plan *plan); /* 4 or 8 */
+int tn_plan_device(const tn_plan *plan);
+int tn_plan_has_fused(const tn_plan *plan);       /* 1 if TN_VARIANT_FUSED is available for this (n, q) */
+int tn_plan_is_lazy(const tn_plan *plan);         /* 1 if the fused kernel runs with lazy reduction */
+
+/*
+ * c[r] = a[r] * b[r] in Z_q[x]/(x^n+1) for r < batch.
+ * Replaces: nwc_poly_mult(a, b, psi_2n) (cg_ntt.py:78-92), nwc_poly_mult_8butterfly
+ * (cg_ntt_8butterfly.py:107-121; use TN_VARIANT_CG8), negacyclic_mul_ntt(a, b, out)
+ * (benchmark_ntt_60bit.cpp:148-159).
+ */
+tn_status tn_poly_mult_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch,
+                           tn_variant variant, void *stream);
+tn_status tn_poly_mult_host(tn_plan *plan, const void *a, const void *b, void *c, size_t batch,
+                            tn_variant variant);
+
+/*
+ * Untwisted cyclic transforms with omega = psi^2, natural order in and out.
+ * tn_ntt_forward_*  replaces cg_ntt(a_prime, omega_n, modulus)  (cg_ntt.py:29-65),
+ *                   cg_ntt_8butterfly (cg_ntt_8butterfly.py:41-97) with TN_VARIANT_CG8.
+ * tn_ntt_inverse_*  replaces cg_intt(A, omega_n, modulus)       (cg_ntt.py:68-75).
+ * Only the CG variants implement these (AUTO selects CG).
+ */
+tn_status tn_ntt_forward_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
+tn_status tn_ntt_inverse_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
+tn_status tn_ntt_forward_host(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant);
+tn_status tn_ntt_inverse_host(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant);
+
+/*
+ * Forward transform of ONE polynomial that also returns every stage's output:
+ * trace is [log2 n][n] elements, row s-1 = the list `A` after stage s — the
+ * data cg_ntt(..., verbose=True) prints 16-at-a-time (cg_ntt.py:60-62).
+ */
+tn_status tn_ntt_forward_trace_host(tn_plan *plan, const void *in, void *out, void *trace, tn_variant variant);
+
+/*
+ * twist + forward transform: the reference's second timed unit,
+ * forward_ntt_bench(a, out) (benchmark_ntt_60bit.cpp:161-165).
+ */
+tn_status tn_twisted_ntt_forward_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
+
+/*
+ * Synthetic inputs and digests, on device, in the reference benchmark's own
+ * conventions so runs can be diffed against its printed checksums:
+ * tn_fill_lcg_dev: row r gets make_poly(seed0 + r * seed_stride)
+ *                  (benchmark_ntt_60bit.cpp:79-87; benchmark_ntt.cpp:82-90 when q < 2^32).
+ * tn_checksum_rows_dev: out[r] = checksum(row r)  (benchmark_ntt_60bit.cpp:182-188;
+ *                  benchmark_ntt.cpp:228-233 when q < 2^32).  out is a DEVICE uint64_t[batch].
+ */
+tn_status tn_fill_lcg_dev(tn_plan *plan, void *dst, size_t batch, uint64_t seed0, uint64_t seed_stride, void *stream);
+tn_status tn_checksum_rows_dev(tn_plan *plan, const void *src, uint64_t *out, size_t batch, void *stream);
+
+/* Blocks until everything enqueued on the plan's own stream has finished. */
+tn_status tn_plan_synchronize(tn_plan *plan);
+
+/*
+ * Times `iters` back-to-back launches of tn_poly_mult_dev on the plan's own
+ * stream with HIP events recorded on that stream (hipEventRecord); returns the
+ * mean milliseconds per launch.  (bench.py uses this so the timed region is
+ * measured on the stream the kernel runs on.)
+ */
+tn_status tn_time_poly_mult_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch,
+                                tn_variant variant, int iters, float *ms_per_launch);
+
+/* Name of the kernel a variant resolves to for this plan (for matching rocprof rows). */
+const char *tn_kernel_name(const tn_plan *plan, tn_variant variant);
+
+const char *tn_last_error(void);
+const char *tn_status_string(tn_status s);
+int tn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYNTT_H */

@@ -1,0 +1,168 @@
+// emu_kernels.cpp — TEST INFRASTRUCTURE: steps the product kernels' per-thread
+// code (tiny_ntt_amd/csrc/fused_core.h, modarith.h, plan_tables.h — the very
+// headers the gfx950 kernels are compiled from) on the CPU, one emulated thread
+// at a time with barriers between phases, so index maps, LDS layouts, table
+// semantics and lazy-reduction bounds can be checked in the GPU-less build
+// container.  Built with g++ by tests/emu/Makefile; loaded by tests/test_emu.py.
+// It is not a product path and nothing in tiny_ntt_amd/ loads it.
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "../../tiny_ntt_amd/csrc/plan_tables.h"
+
+using namespace tn;
+
+namespace {
+
+template <typename E, int LOGN, int LPT, bool LAZY>
+int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  typedef Policy<E, LAZY> Pol;
+  typedef typename TwOf<E>::type Tw;
+  const Arith<E> ar = h_make_arith<E>(t);
+  const std::vector<Tw> psi_brv = h_tw_table<E>(t.psi_brv, t.q), psi_inv_brv = h_tw_table<E>(t.psi_inv_brv, t.q);
+  std::vector<E> lds(Cfg::lds_elems());
+  struct Regs { E x[Cfg::R]; };
+  std::vector<Regs> xa(Cfg::THREADS), xb(Cfg::THREADS);
+
+  auto forward = [&](std::vector<Regs>& x) {
+    static_for<0, Cfg::PHASES>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) fwd_phase<E, Cfg, Pol, p>(x[tau].x, tau, psi_brv.data(), ar);
+      if constexpr (p + 1 < Cfg::PHASES) {
+        for (auto& v : lds) v = (E)0xDEADBEEFu;
+        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p, p>(x[tau].x, tau, lds.data());
+        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_load<E, Cfg, p, p + 1>(x[tau].x, tau, lds.data());
+      }
+    });
+  };
+  auto inverse = [&](std::vector<Regs>& x) {
+    static_for<0, Cfg::PHASES>([&](auto i_) {
+      constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
+      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) inv_phase<E, Cfg, Pol, p>(x[tau].x, tau, psi_inv_brv.data(), ar);
+      if constexpr (p > 0) {
+        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p - 1, p>(x[tau].x, tau, lds.data());
+        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_load<E, Cfg, p - 1, p - 1>(x[tau].x, tau, lds.data());
+      }
+    });
+  };
+
+  for (size_t row = 0; row < batch; ++row) {
+    const size_t off = row << LOGN;
+    for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
+      for (int r = 0; r < Cfg::R; ++r) {
+        xa[tau].x[r] = Pol::load((E)a[off + Cfg::jidx(0, tau, r)], ar);
+        xb[tau].x[r] = Pol::load((E)b[off + Cfg::jidx(0, tau, r)], ar);
+      }
+    forward(xa);
+    forward(xb);
+    for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) pointwise<E, Cfg, Pol>(xa[tau].x, xb[tau].x, ar);
+    inverse(xa);
+    for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
+      for (int r = 0; r < Cfg::R; ++r) c[off + Cfg::jidx(0, tau, r)] = xa[tau].x[r];
+  }
+  return 0;
+}
+
+template <typename E, bool LAZY>
+int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch) {
+  switch (t.logn) {
+    case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch);
+    case 10: return fused_polymul_emu<E, 10, 4, LAZY>(t, a, b, c, batch);
+    case 12: return fused_polymul_emu<E, 12, 4, LAZY>(t, a, b, c, batch);
+    default: return 7;
+  }
+}
+
+// Sequential restatement of cg_kernel's arithmetic with the product's tables
+// and modarith (thread mapping there is a plain strided loop).
+template <typename E>
+int cg_emu(const HostTables& t, int mode, const u64* a, const u64* b, u64* out, u64* trace) {
+  typedef typename TwOf<E>::type Tw;
+  const Arith<E> ar = h_make_arith<E>(t);
+  const u32 n = t.n, logn = t.logn, pairs = n / 2;
+  const std::vector<Tw> omega = h_tw_table<E>(t.omega_pow, t.q), omega_inv = h_tw_table<E>(t.omega_inv_pow, t.q),
+                        psi_pow = h_tw_table<E>(t.psi_pow, t.q), psi_inv_ninv = h_tw_table<E>(t.psi_inv_ninv, t.q);
+  auto load_brv = [&](const u64* in, const Tw* tw) {
+    std::vector<E> buf(n);
+    for (u32 i = 0; i < n; ++i) buf[h_brv(i, logn)] = tw ? mul_tw((E)in[i], tw[i], ar.q) : mul_tw((E)in[i], ar.one, ar.q);
+    return buf;
+  };
+  auto stages = [&](std::vector<E> src, const Tw* tab, u64* tr) {
+    std::vector<E> dst(n);
+    for (u32 stage = 1; stage <= logn; ++stage) {
+      const u32 k = n >> stage;
+      for (u32 i = 0; i < pairs; ++i) {
+        const E left = src[2 * i], right = src[2 * i + 1];
+        const E tt = mul_tw(right, tab[i & ~(k - 1)], ar.q);
+        dst[i] = csub((E)(left + tt), ar.q);
+        dst[i + pairs] = left >= tt ? (E)(left - tt) : (E)(left + (ar.q - tt));
+      }
+      if (tr) for (u32 i = 0; i < n; ++i) tr[(size_t)(stage - 1) * n + i] = dst[i];
+      src.swap(dst);
+    }
+    return src;
+  };
+  if (mode == 0 || mode == 3) {
+    auto r = stages(load_brv(a, mode == 3 ? psi_pow.data() : nullptr), omega.data(), trace);
+    for (u32 i = 0; i < n; ++i) out[i] = r[i];
+  } else if (mode == 1) {
+    auto r = stages(load_brv(a, nullptr), omega_inv.data(), nullptr);
+    for (u32 i = 0; i < n; ++i) out[i] = mul_tw(r[i], ar.ninv, ar.q);
+  } else {
+    auto ra = stages(load_brv(a, psi_pow.data()), omega.data(), nullptr);
+    auto rb = stages(load_brv(b, psi_pow.data()), omega.data(), nullptr);
+    std::vector<E> cc(n);
+    for (u32 i = 0; i < n; ++i) cc[h_brv(i, logn)] = mulmod_barrett(ra[i], rb[i], ar.q, ar.mu, ar.k);
+    auto rc = stages(cc, omega_inv.data(), nullptr);
+    for (u32 i = 0; i < n; ++i) out[i] = mul_tw(rc[i], psi_inv_ninv[i], ar.q);
+  }
+  return 0;
+}
+
+bool params_ok(u32 n, u64 q, u64 psi) {
+  if (n < 4 || (n & (n - 1)) || q < 3 || !(q & 1) || q >= ((u64)1 << 62)) return false;
+  return h_powmod(psi % q, n, q) == q - 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 0 ok, 2 bad params, 7 unsupported n.  Coefficients travel as uint64 regardless of lane width.
+int emu_fused_poly_mult(uint32_t n, uint64_t q, uint64_t psi, int force_canonical, const uint64_t* a, const uint64_t* b,
+                        uint64_t* c, size_t batch) {
+  if (!params_ok(n, q, psi)) return 2;
+  const HostTables t = h_build_tables(n, q, psi, !force_canonical);
+  if (t.elem_bytes == 8) return t.lazy ? fused_dispatch<u64, true>(t, a, b, c, batch) : fused_dispatch<u64, false>(t, a, b, c, batch);
+  return t.lazy ? fused_dispatch<u32, true>(t, a, b, c, batch) : fused_dispatch<u32, false>(t, a, b, c, batch);
+}
+
+int emu_is_lazy(uint32_t n, uint64_t q, uint64_t psi) {
+  if (!params_ok(n, q, psi)) return -1;
+  return h_build_tables(n, q, psi, true).lazy ? 1 : 0;
+}
+
+// mode: 0 cg_ntt, 1 cg_intt, 2 nwc_poly_mult, 3 twist + cg_ntt.  trace may be NULL ([logn][n] otherwise, mode 0/3).
+int emu_cg(uint32_t n, uint64_t q, uint64_t psi, int mode, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t* trace) {
+  if (!params_ok(n, q, psi)) return 2;
+  const HostTables t = h_build_tables(n, q, psi, true);
+  return t.elem_bytes == 8 ? cg_emu<u64>(t, mode, a, b, out, trace) : cg_emu<u32>(t, mode, a, b, out, trace);
+}
+
+// Direct probes of the arithmetic primitives (for property tests).
+uint64_t emu_mul_tw64(uint64_t a, uint64_t w, uint64_t q) { return mul_tw(a, h_make_tw64(w, q), q); }
+uint64_t emu_mul_tw64_lazy(uint64_t a, uint64_t w, uint64_t q) { return mul_tw_lazy(a, h_make_tw64(w, q), q); }
+uint32_t emu_mul_tw32(uint32_t a, uint32_t w, uint32_t q) { return mul_tw(a, h_make_tw32(w, q), q); }
+uint64_t emu_barrett64(uint64_t a, uint64_t b, uint64_t q) {
+  const int k = h_bitlen(q);
+  return mulmod_barrett(a, b, q, (u64)((((unsigned __int128)1) << (2 * k)) / q), k);
+}
+uint32_t emu_barrett32(uint32_t a, uint32_t b, uint32_t q) {
+  const int k = h_bitlen(q);
+  return mulmod_barrett(a, b, q, (u64)((((unsigned __int128)1) << (2 * k)) / q), k);
+}
+uint64_t emu_fold64(uint64_t x, uint64_t q) { const int k = h_bitlen(q); return fold(x, k, (u32)((((u64)1) << k) - q)); }
+uint32_t emu_fold32(uint32_t x, uint32_t q) { const int k = h_bitlen(q); return fold(x, k, (u32)((((u64)1) << k) - q)); }
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the
+reference's Python golden model (new_reference/cg_ntt.py, cg_ntt_8butterfly.py).
+
+Run only in the build container, where /root/reference exists:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Nothing from the reference is copied: the fixtures hold inputs and the outputs
+the reference computed for them (numpy .npz, uint64 little-endian).  The GPU box
+has no /root/reference; tests read only the committed .npz / .json files.
+
+Parameterisation (SURVEY.md §7 "parameterisation trap"): the module hard-codes
+N=256, Q=8380417; cg_ntt/cg_intt read N at call time and take `modulus`
+explicitly, so N and Q are overridden on both modules and `modulus` is always
+passed.
+"""
+import ast
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+REF = os.environ.get("TINY_NTT_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "new_reference"))
+import cg_ntt as ref          # noqa: E402
+import cg_ntt_8butterfly as ref8   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+PARAMS = {
+    # tag: (n, q, psi)        source of the parameter set
+    "P4":       (4, 7681, 1925),                                   # test/refs/fast_ntt_negacyclic_convolution.py:161-214
+    "P256":     (256, 8380417, 1239911),                           # new_reference/test_cg_ntt.py:7
+    "P1024":    (1024, 8380417, 5548360),                          # test/Makefile:268
+    "P4096":    (4096, 8380417, 283817),                           # software_benchmark/CMakeLists.txt:5-7
+    "P4096_60": (4096, 1152921504606830593, 431606828070683274),   # rtl/ntt_poly_mult.sv:16-24
+}
+
+
+def set_params(n, q):
+    ref.N, ref.Q = n, q
+    ref8.N, ref8.Q = n, q
+
+
+def lcg_poly(seed, n, q):
+    """Inputs of the reference C++ benchmark (make_poly): benchmark_ntt_60bit.cpp:79-87 / benchmark_ntt.cpp:82-90."""
+    x, out = seed, []
+    for _ in range(n):
+        x = (6364136223846793005 * x + 1442695040888963407) & ((1 << 64) - 1)
+        out.append((x >> 17) % q if q < (1 << 32) else x % q)
+    return out
+
+
+def trace_of(fn, a, omega, q):
+    """Run the reference with verbose=True and collect its per-stage 'first 16' lines."""
+    lines = []
+    out = fn(a, omega, q, True, lines.append)
+    stages = [ast.literal_eval(s.split("=", 1)[1]) for s in lines if s.startswith("  stage_out(first 16)=")]
+    bitrev = [ast.literal_eval(s.split("=", 1)[1]) for s in lines if s.startswith("  bitrev(first 16)=")]
+    return out, stages, bitrev[0]
+
+
+def u64(x):
+    return np.asarray(x, dtype=np.uint64)
+
+
+def gen(tag):
+    n, q, psi = PARAMS[tag]
+    set_params(n, q)
+    omega = pow(psi, 2, q)
+    arrays, meta = {}, {"n": n, "q": q, "psi": psi, "omega": omega, "cases": []}
+
+    def poly_case(name, a, b):
+        c = ref.nwc_poly_mult(list(a), list(b), psi)
+        c8 = ref8.nwc_poly_mult_8butterfly(list(a), list(b), psi)
+        assert c == c8
+        arrays[name + "_a"], arrays[name + "_b"], arrays[name + "_c"] = u64(a), u64(b), u64(c)
+        meta["cases"].append({"name": name, "kind": "poly_mult"})
+        return c
+
+    def ntt_case(name, a):
+        A, stages, bitrev16 = trace_of(ref.cg_ntt, list(a), omega, q)
+        A8, stages8, _ = trace_of(ref8.cg_ntt_8butterfly, list(a), omega, q)
+        assert A == A8 and stages == stages8
+        back = ref.cg_intt(list(A), omega, q)
+        assert back == [x % q for x in a]
+        assert ref8.cg_intt_8butterfly(list(A), omega, q) == back
+        arrays[name + "_x"], arrays[name + "_X"] = u64(a), u64(A)
+        w = min(16, n)
+        arrays[name + "_trace16"] = u64([s[:w] for s in stages])
+        arrays[name + "_bitrev16"] = u64(bitrev16[:w])
+        meta["cases"].append({"name": name, "kind": "ntt"})
+
+    # seeded random cases, in the exact RNG call order of the reference tests
+    # (test_cg_ntt.py:44-52,92-95; test_cg_ntt_8butterfly.py:49-51,60-62,108-111)
+    seeds_ntt = [0, 2, 3] if tag == "P256" else [0]
+    for s in seeds_ntt:
+        random.seed(s)
+        ntt_case(f"seed{s}_ntt", [random.randrange(q) for _ in range(n)])
+    seeds_mul = [1, 4] if tag == "P256" else [1]
+    for s in seeds_mul:
+        random.seed(s)
+        a = [random.randrange(q) for _ in range(n)]
+        b = [random.randrange(q) for _ in range(n)]
+        poly_case(f"seed{s}_mul", a, b)
+
+    def sparse(vals):
+        return list(vals) + [0] * (n - len(vals))
+
+    if n >= 4:
+        # hand KATs: test_cg_ntt.py:55-89, test/cocotb_tests/test_ntt_inverse.py:273-275
+        if n >= 8:
+            assert poly_case("kat_123x456", sparse([1, 2, 3]), sparse([4, 5, 6]))[:6] == [4, 13, 28, 27, 18, 0]
+        c = poly_case("kat_123x51", sparse([1, 2, 3]), sparse([5, 1]))
+        if n >= 8:
+            assert c[:5] == [5, 11, 17, 3, 0]
+        poly_case("kat_151x51", sparse([1, 5, 1]), sparse([5, 1]))
+    # shapes of test/cocotb_tests/test_ntt_forward.py:246-453
+    ntt_case("zeros_ntt", [0] * n)
+    ntt_case("impulse_ntt", sparse([1]))
+    ntt_case("ones_ntt", [1] * n)
+    ntt_case("counting_ntt", [i % q for i in range(n)])
+    ntt_case("qm1_ntt", [q - 1] * n)
+    # boundary products: all q-1, and the wrap-around monomial x^(n-1) * x = -1
+    poly_case("qm1_mul", [q - 1] * n, [q - 1] * n)
+    xm, x1 = [0] * n, [0] * n
+    xm[n - 1], x1[1] = 1, 1
+    c = poly_case("wrap_mul", xm, x1)
+    assert c[0] == q - 1 and not any(c[1:])
+    poly_case("zeros_mul", [0] * n, [q - 1] * n)
+    # the reference C++ benchmark's own inputs (checksums G1-G3 of SURVEY.md §8c)
+    if tag != "P4":
+        a, b = lcg_poly(1, n, q), lcg_poly(2, n, q)
+        poly_case("lcg12_mul", a, b)
+        twisted = [(a[i] * pow(psi, i, q)) % q for i in range(n)]
+        arrays["lcg1_fwd"] = u64(ref.cg_ntt(twisted, omega, q))
+        meta["cases"].append({"name": "lcg1_fwd", "kind": "forward_ntt_bench"})
+    if tag == "P4":
+        # literature KAT (fast_ntt_negacyclic_convolution.py:161-214)
+        g, h = [1, 2, 3, 4], [5, 6, 7, 8]
+        assert poly_case("lit_mul", g, h) == [7625, 7645, 2, 60]
+        tw = [(g[i] * pow(psi, i, q)) % q for i in range(n)]
+        assert ref.cg_ntt(tw, omega, q) == [1467, 2807, 3471, 7621]
+
+    np.savez_compressed(os.path.join(HERE, f"golden_{tag}.npz"), **arrays)
+    with open(os.path.join(HERE, f"golden_{tag}.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(tag, "cases:", len(meta["cases"]), "arrays:", len(arrays))
+
+
+if __name__ == "__main__":
+    for tag in PARAMS:
+        gen(tag)

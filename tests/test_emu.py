@@ -1,0 +1,120 @@
+"""CPU stepping of the product kernels' per-thread code (tests/emu) against golden vectors and the
+oracle: validates index maps, LDS layouts, table semantics, lazy-reduction bounds and the modular
+primitives of tiny_ntt_amd/csrc/*.h without a GPU."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import PARAMS
+
+FUSED_TAGS = ["P256", "P1024", "P4096", "P4096_60"]
+
+
+@pytest.mark.parametrize("tag", FUSED_TAGS)
+@pytest.mark.parametrize("canonical", [False, True])
+def test_fused_emulation_matches_golden(emu, golden, tag, canonical):
+    g = golden(tag)
+    for name in g.cases("poly_mult"):
+        c = emu.fused(g.n, g.q, g.psi, g[name + "_a"], g[name + "_b"], canonical=canonical)
+        assert np.array_equal(c, g[name + "_c"]), name
+
+
+@pytest.mark.parametrize("tag", FUSED_TAGS)
+def test_fused_emulation_random_and_unreduced_vs_oracle(emu, oracle, tag):
+    n, q, psi = PARAMS[tag]
+    rng = np.random.default_rng(2)
+    word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1
+    a = rng.integers(0, q, (6, n), dtype=np.uint64); b = rng.integers(0, q, (6, n), dtype=np.uint64)
+    a[0] = q - 1; b[0] = q - 1
+    a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b[1] = word      # any word value is taken mod q
+    a[2] = word; b[2] = word
+    ref = oracle.poly_mult(a, b, q, psi)
+    for canonical in (False, True):
+        assert np.array_equal(emu.fused(n, q, psi, a, b, canonical=canonical), ref)
+
+
+def test_lazy_policy_selected_for_reference_moduli(emu):
+    for tag in FUSED_TAGS:
+        assert emu.lib.emu_is_lazy(*PARAMS[tag]) == 1, tag
+    # a generic 30-bit NTT prime far from a power of two must fall back to canonical arithmetic
+    q, n = 754974721, 256                      # 45 * 2^24 + 1
+    g = next(pow(x, (q - 1) // (2 * n), q) for x in range(2, 50) if pow(pow(x, (q - 1) // (2 * n), q), n, q) == q - 1)
+    assert emu.lib.emu_is_lazy(n, q, g) == 0
+
+
+def test_fused_emulation_generic_modulus_canonical(emu, oracle):
+    q, n = 754974721, 256
+    psi = next(pow(x, (q - 1) // (2 * n), q) for x in range(2, 50) if pow(pow(x, (q - 1) // (2 * n), q), n, q) == q - 1)
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
+    assert np.array_equal(emu.fused(n, q, psi, a, b), oracle.poly_mult(a, b, q, psi))
+    # 61-bit prime (k * 2^20 + 1): 16q > 2^64, so 64-bit lanes must use the canonical policy
+    q = 2305843009196916737
+    psi = next(pow(x, (q - 1) // (2 * n), q) for x in range(2, 200) if pow(pow(x, (q - 1) // (2 * n), q), n, q) == q - 1)
+    assert emu.lib.emu_is_lazy(n, q, psi) == 0
+    a = rng.integers(0, q, (2, n), dtype=np.uint64); b = rng.integers(0, q, (2, n), dtype=np.uint64)
+    a[0] = q - 1; b[0] = q - 1
+    assert np.array_equal(emu.fused(n, q, psi, a, b), oracle.poly_mult(a, b, q, psi))
+
+
+@pytest.mark.parametrize("tag", ["P4", "P256", "P1024", "P4096", "P4096_60"])
+def test_cg_emulation_matches_golden(emu, golden, tag):
+    g = golden(tag)
+    for name in g.cases("poly_mult"):
+        assert np.array_equal(emu.cg(g.n, g.q, g.psi, 2, g[name + "_a"], g[name + "_b"]), g[name + "_c"]), name
+    for name in g.cases("ntt"):
+        out, tr = emu.cg(g.n, g.q, g.psi, 0, g[name + "_x"], trace=True)
+        assert np.array_equal(out, g[name + "_X"]), name
+        assert np.array_equal(tr[:, :min(16, g.n)], g[name + "_trace16"]), name
+        assert np.array_equal(emu.cg(g.n, g.q, g.psi, 1, g[name + "_X"]), g[name + "_x"] % np.uint64(g.q)), name
+    if tag != "P4":
+        assert np.array_equal(emu.cg(g.n, g.q, g.psi, 3, g["lcg12_mul_a"]), g["lcg1_fwd"])
+
+
+EDGE64 = [0, 1, 2, 2 ** 32 - 1, 2 ** 32, 2 ** 60 - 1, 2 ** 60, 2 ** 63, 2 ** 64 - 1]
+
+
+def test_mul_tw64_exact_for_any_word(emu):
+    rnd = random.Random(1)
+    for q in (PARAMS["P4096_60"][1], 2305843009213693951 - 2 ** 20 + 2 ** 20, 4611686018326724609):   # 60-bit, 2^61-1, ~2^62
+        ws = [0, 1, q - 1, q // 2] + [rnd.randrange(q) for _ in range(300)]
+        xs = EDGE64 + [q - 1, q, q + 1, 2 * q, 3 * q] + [rnd.randrange(2 ** 64) for _ in range(300)]
+        for w in ws:
+            for a in xs[:40] if w > 3 else xs:
+                a %= 2 ** 64
+                assert emu.lib.emu_mul_tw64(a, w, q) == a * w % q
+                lazy = emu.lib.emu_mul_tw64_lazy(a, w, q)
+                assert lazy < 3 * q and lazy % q == a * w % q
+
+
+def test_mul_tw32_and_barrett32(emu):
+    rnd = random.Random(2)
+    for q in (8380417, 7681, 754974721, 2147483647):
+        vals = [0, 1, q - 1, q // 2] + [rnd.randrange(q) for _ in range(200)]
+        for w in vals[:60]:
+            for a in [0, 1, q - 1, q, 2 ** 32 - 1, 2 ** 31] + [rnd.randrange(2 ** 32) for _ in range(60)]:
+                assert emu.lib.emu_mul_tw32(a, w, q) == a * w % q
+        for a in vals:
+            for b in vals[:40]:
+                assert emu.lib.emu_barrett32(a, b, q) == a * b % q
+
+
+def test_barrett64_boundaries(emu):
+    rnd = random.Random(3)
+    for q in (PARAMS["P4096_60"][1], 4611686018326724609, 2 ** 61 - 1, 1099511627689):
+        vals = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1] + [rnd.randrange(q) for _ in range(400)]
+        for a in vals[:80]:
+            for b in vals:
+                assert emu.lib.emu_barrett64(a, b, q) == a * b % q
+
+
+def test_fold_bounds(emu):
+    q60, q23 = PARAMS["P4096_60"][1], 8380417
+    rnd = random.Random(4)
+    for x in EDGE64 + [rnd.randrange(2 ** 64) for _ in range(2000)]:
+        r = emu.lib.emu_fold64(x, q60)
+        assert r % q60 == x % q60 and r < 2 * q60
+    for x in [0, 1, 2 ** 23, 2 ** 32 - 1, 2 ** 31] + [rnd.randrange(2 ** 32) for _ in range(2000)]:
+        r = emu.lib.emu_fold32(x, q23)
+        assert r % q23 == x % q23 and r < 2 * q23

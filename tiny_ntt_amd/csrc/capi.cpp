@@ -1,0 +1,295 @@
+// capi.cpp — the extern "C" surface declared in include/tinyntt.h: plan
+// creation (validation + exact table generation on the host), the launch entry
+// points, host-buffer conveniences, timing helper.  No CPU compute fallback
+// exists: without a HIP device every entry point fails with TN_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <new>
+#include "../../include/tinyntt.h"
+#include "plan.h"
+#include "plan_tables.h"
+
+using namespace tn;
+
+static thread_local std::string g_err;
+
+static tn_status fail(tn_status s, const std::string& msg) { g_err = msg; return s; }
+static tn_status fail_hip(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return TN_EHIP;
+}
+#define TN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_, #call); } while (0)
+
+extern "C" const char* tn_last_error(void) { return g_err.c_str(); }
+extern "C" int tn_version(void) { return TN_VERSION; }
+extern "C" const char* tn_status_string(tn_status s) {
+  switch (s) {
+    case TN_OK: return "ok";
+    case TN_EBADLEN: return "bad length";
+    case TN_EBADPARAM: return "bad parameter";
+    case TN_ENODEVICE: return "no HIP device";
+    case TN_EHIP: return "HIP runtime error";
+    case TN_ENOMEM: return "out of memory";
+    case TN_EINVAL: return "invalid argument";
+    case TN_EUNSUPPORTED: return "unsupported";
+  }
+  return "unknown";
+}
+
+// Upload a table of constants as Tw32[] or Tw64[] (value + Barrett quotient factor).
+static hipError_t upload_tw(const std::vector<u64>& vals, u64 q, int elem_bytes, void** dptr) {
+  hipError_t e;
+  if (elem_bytes == 8) {
+    std::vector<Tw64> t(vals.size());
+    for (size_t i = 0; i < vals.size(); ++i) t[i] = h_make_tw64(vals[i], q);
+    if ((e = hipMalloc(dptr, t.size() * sizeof(Tw64))) != hipSuccess) return e;
+    return hipMemcpy(*dptr, t.data(), t.size() * sizeof(Tw64), hipMemcpyHostToDevice);
+  }
+  std::vector<Tw32> t(vals.size());
+  for (size_t i = 0; i < vals.size(); ++i) t[i] = h_make_tw32(vals[i], q);
+  if ((e = hipMalloc(dptr, t.size() * sizeof(Tw32))) != hipSuccess) return e;
+  return hipMemcpy(*dptr, t.data(), t.size() * sizeof(Tw32), hipMemcpyHostToDevice);
+}
+
+static void set_tw(u64 w, u64 q, int elem_bytes, u64* ow, u64* owp) {
+  if (elem_bytes == 8) { Tw64 t = h_make_tw64(w, q); *ow = t.w; *owp = t.wp; }
+  else { Tw32 t = h_make_tw32(w, q); *ow = t.w; *owp = t.wp; }
+}
+
+extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags) {
+  if (!out) return fail(TN_EINVAL, "tn_plan_create: out is NULL");
+  *out = nullptr;
+  u32 logn = 0;
+  while (((u32)1 << logn) < n) ++logn;
+  if (n < 4 || ((u32)1 << logn) != n) {
+    char buf[96]; snprintf(buf, sizeof buf, "Expected a power-of-two length >= 4, got %u", n);
+    return fail(TN_EBADLEN, buf);
+  }
+  if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
+  if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
+  const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
+  if (n > (elem_bytes == 8 ? 4096u : 8192u)) {
+    char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
+    return fail(TN_EBADLEN, buf);
+  }
+  psi %= q;
+  if (h_powmod(psi, n, q) != q - 1)
+    return fail(TN_EBADPARAM, "psi must satisfy psi^n == -1 mod q (primitive 2n-th root; benchmark_ntt_60bit.cpp:58-59)");
+
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev <= 0)
+    return fail(TN_ENODEVICE, "no HIP device visible; libtinyntt has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(TN_EINVAL, "device index out of range");
+  TN_HIP(hipSetDevice(device));
+
+  tn_plan* p = new (std::nothrow) tn_plan();
+  if (!p) return fail(TN_ENOMEM, "plan allocation failed");
+  const HostTables t = h_build_tables(n, q, psi, !(flags & TN_PLAN_FORCE_CANONICAL));
+  p->n = n; p->logn = logn; p->q = q; p->psi = psi; p->omega = t.omega;
+  p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
+  p->k = t.k; p->mu = t.mu; p->lazy = t.lazy; p->fold_c = t.fold_c;
+  p->has_fused = fused_supported(logn, elem_bytes);
+  set_tw(1, q, elem_bytes, &p->one_w, &p->one_wp);
+  set_tw(t.n_inv, q, elem_bytes, &p->ninv_w, &p->ninv_wp);
+  set_tw(t.ninv_w1, q, elem_bytes, &p->ninv_w1_w, &p->ninv_w1_wp);
+
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = upload_tw(t.psi_brv, q, elem_bytes, &p->d_psi_brv);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_brv, q, elem_bytes, &p->d_psi_inv_brv);
+  if (e == hipSuccess) e = upload_tw(t.omega_pow, q, elem_bytes, &p->d_omega_pow);
+  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, q, elem_bytes, &p->d_omega_inv_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_pow, q, elem_bytes, &p->d_psi_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, q, elem_bytes, &p->d_psi_inv_ninv);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+  if (e != hipSuccess) { tn_plan_destroy(p); return fail_hip(e, "plan table upload"); }
+  *out = p;
+  return TN_OK;
+}
+
+extern "C" tn_status tn_plan_destroy(tn_plan* p) {
+  if (!p) return TN_OK;
+  (void)hipSetDevice(p->device);
+  void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_scratch};
+  for (void* t : tabs) if (t) (void)hipFree(t);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return TN_OK;
+}
+
+extern "C" uint32_t tn_plan_n(const tn_plan* p) { return p ? p->n : 0; }
+extern "C" uint64_t tn_plan_q(const tn_plan* p) { return p ? p->q : 0; }
+extern "C" uint64_t tn_plan_psi(const tn_plan* p) { return p ? p->psi : 0; }
+extern "C" uint64_t tn_plan_omega(const tn_plan* p) { return p ? p->omega : 0; }
+extern "C" uint32_t tn_plan_elem_bytes(const tn_plan* p) { return p ? (uint32_t)p->elem_bytes : 0; }
+extern "C" int tn_plan_device(const tn_plan* p) { return p ? p->device : -1; }
+extern "C" int tn_plan_has_fused(const tn_plan* p) { return p && p->has_fused; }
+extern "C" int tn_plan_is_lazy(const tn_plan* p) { return p && p->lazy; }
+
+static hipStream_t pick_stream(tn_plan* p, void* stream) { return stream ? (hipStream_t)stream : p->stream; }
+
+struct CgSel { int group; bool padded; };
+static bool cg_sel(tn_variant v, CgSel* s) {
+  switch (v) {
+    case TN_VARIANT_CG: *s = {1, false}; return true;
+    case TN_VARIANT_CG8: *s = {8, false}; return true;
+    case TN_VARIANT_CG8_PADDED: *s = {8, true}; return true;
+    default: return false;
+  }
+}
+
+static tn_status check_ptrs(const tn_plan* p, const void* a, const void* b, const void* c, size_t batch, const char* fn) {
+  if (!p) return fail(TN_EINVAL, std::string(fn) + ": plan is NULL");
+  if (batch > 0xffffffffull) return fail(TN_EINVAL, std::string(fn) + ": batch too large for one call");
+  if (batch && (!a || !b || !c)) return fail(TN_EINVAL, std::string(fn) + ": NULL buffer");
+  if (batch && (c == a || c == b)) return fail(TN_EINVAL, std::string(fn) + ": output must not alias an input");
+  return TN_OK;
+}
+
+extern "C" tn_status tn_poly_mult_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant,
+                                      void* stream) {
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_dev");
+  if (st) return st;
+  TN_HIP(hipSetDevice(p->device));
+  hipStream_t s = pick_stream(p, stream);
+  if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
+  if (variant == TN_VARIANT_FUSED) {
+    if (!p->has_fused) return fail(TN_EUNSUPPORTED, "fused kernel not built for this n; use TN_VARIANT_CG");
+    TN_HIP(launch_polymul_fused(p, a, b, c, batch, s));
+    return TN_OK;
+  }
+  CgSel sel;
+  if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, "unknown variant");
+  TN_HIP(launch_cg(p, CG_POLYMUL, sel.group, sel.padded, a, b, c, nullptr, batch, s));
+  return TN_OK;
+}
+
+static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t batch, tn_variant variant, void* stream,
+                         void* trace, const char* fn) {
+  tn_status st = check_ptrs(p, in, in, out, batch, fn);
+  if (st) return st;
+  TN_HIP(hipSetDevice(p->device));
+  if (variant == TN_VARIANT_AUTO) variant = TN_VARIANT_CG;
+  CgSel sel;
+  if (!cg_sel(variant, &sel)) return fail(TN_EUNSUPPORTED, std::string(fn) + ": only the CG variants implement the untwisted transforms");
+  TN_HIP(launch_cg(p, mode, sel.group, sel.padded, in, nullptr, out, trace, batch, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_ntt_forward_dev(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v, void* stream) {
+  return ntt_dev(p, CG_NTT_FWD, in, out, batch, v, stream, nullptr, "tn_ntt_forward_dev");
+}
+extern "C" tn_status tn_ntt_inverse_dev(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v, void* stream) {
+  return ntt_dev(p, CG_NTT_INV, in, out, batch, v, stream, nullptr, "tn_ntt_inverse_dev");
+}
+extern "C" tn_status tn_twisted_ntt_forward_dev(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v, void* stream) {
+  return ntt_dev(p, CG_TWIST_FWD, in, out, batch, v, stream, nullptr, "tn_twisted_ntt_forward_dev");
+}
+
+// ---- host-buffer conveniences ------------------------------------------------
+static tn_status ensure_scratch(tn_plan* p, size_t bytes) {
+  if (bytes <= p->scratch_bytes) return TN_OK;
+  if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+  hipError_t e = hipMalloc(&p->d_scratch, bytes);
+  if (e != hipSuccess) return fail(TN_ENOMEM, std::string("device scratch allocation failed: ") + hipGetErrorString(e));
+  p->scratch_bytes = bytes;
+  return TN_OK;
+}
+
+extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant) {
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_host");
+  if (st || batch == 0) return st;
+  TN_HIP(hipSetDevice(p->device));
+  const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
+  if ((st = ensure_scratch(p, 3 * bytes))) return st;
+  char* d = (char*)p->d_scratch;
+  TN_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, p->stream));
+  TN_HIP(hipMemcpyAsync(d + bytes, b, bytes, hipMemcpyHostToDevice, p->stream));
+  if ((st = tn_poly_mult_dev(p, d, d + bytes, d + 2 * bytes, batch, variant, nullptr))) return st;
+  TN_HIP(hipMemcpyAsync(c, d + 2 * bytes, bytes, hipMemcpyDeviceToHost, p->stream));
+  TN_HIP(hipStreamSynchronize(p->stream));
+  return TN_OK;
+}
+
+static tn_status ntt_host(tn_plan* p, int mode, const void* in, void* out, void* trace, size_t batch, tn_variant v, const char* fn) {
+  tn_status st = check_ptrs(p, in, in, out, batch, fn);
+  if (st || batch == 0) return st;
+  TN_HIP(hipSetDevice(p->device));
+  const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
+  const size_t tbytes = trace ? bytes * p->logn : 0;
+  if ((st = ensure_scratch(p, 2 * bytes + tbytes))) return st;
+  char* d = (char*)p->d_scratch;
+  TN_HIP(hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, p->stream));
+  if ((st = ntt_dev(p, mode, d, d + bytes, batch, v, nullptr, trace ? d + 2 * bytes : nullptr, fn))) return st;
+  TN_HIP(hipMemcpyAsync(out, d + bytes, bytes, hipMemcpyDeviceToHost, p->stream));
+  if (trace) TN_HIP(hipMemcpyAsync(trace, d + 2 * bytes, tbytes, hipMemcpyDeviceToHost, p->stream));
+  TN_HIP(hipStreamSynchronize(p->stream));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_ntt_forward_host(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v) {
+  return ntt_host(p, CG_NTT_FWD, in, out, nullptr, batch, v, "tn_ntt_forward_host");
+}
+extern "C" tn_status tn_ntt_inverse_host(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v) {
+  return ntt_host(p, CG_NTT_INV, in, out, nullptr, batch, v, "tn_ntt_inverse_host");
+}
+extern "C" tn_status tn_ntt_forward_trace_host(tn_plan* p, const void* in, void* out, void* trace, tn_variant v) {
+  if (!trace) return fail(TN_EINVAL, "tn_ntt_forward_trace_host: trace is NULL");
+  return ntt_host(p, CG_NTT_FWD, in, out, trace, 1, v, "tn_ntt_forward_trace_host");
+}
+
+extern "C" tn_status tn_fill_lcg_dev(tn_plan* p, void* dst, size_t batch, uint64_t seed0, uint64_t seed_stride, void* stream) {
+  if (!p || (batch && !dst)) return fail(TN_EINVAL, "tn_fill_lcg_dev: NULL argument");
+  if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_fill_lcg_dev: batch too large");
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(launch_fill_lcg(p, dst, batch, seed0, seed_stride, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_checksum_rows_dev(tn_plan* p, const void* src, uint64_t* out, size_t batch, void* stream) {
+  if (!p || (batch && (!src || !out))) return fail(TN_EINVAL, "tn_checksum_rows_dev: NULL argument");
+  if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_checksum_rows_dev: batch too large");
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(launch_checksum(p, src, out, batch, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_plan_synchronize(tn_plan* p) {
+  if (!p) return fail(TN_EINVAL, "tn_plan_synchronize: plan is NULL");
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(hipStreamSynchronize(p->stream));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_time_poly_mult_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant,
+                                           int iters, float* ms_per_launch) {
+  if (!ms_per_launch || iters < 1) return fail(TN_EINVAL, "tn_time_poly_mult_dev: bad iters/ms pointer");
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_time_poly_mult_dev");
+  if (st) return st;
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(hipEventRecord(p->ev0, p->stream));
+  for (int i = 0; i < iters; ++i)
+    if ((st = tn_poly_mult_dev(p, a, b, c, batch, variant, nullptr))) return st;
+  TN_HIP(hipEventRecord(p->ev1, p->stream));
+  TN_HIP(hipEventSynchronize(p->ev1));
+  float ms = 0.f;
+  TN_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  *ms_per_launch = ms / (float)iters;
+  return TN_OK;
+}
+
+extern "C" const char* tn_kernel_name(const tn_plan* p, tn_variant variant) {
+  if (!p) return "";
+  if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
+  if (variant == TN_VARIANT_FUSED) return fused_kernel_name(p);
+  CgSel sel;
+  if (cg_sel(variant, &sel)) return cg_kernel_name(p, sel.group, sel.padded);
+  return "";
+}

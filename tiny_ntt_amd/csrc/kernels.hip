@@ -1,0 +1,344 @@
+// kernels.hip — gfx950 kernels of libtinyntt and their launchers.
+//
+//  polymul_fused_kernel : K6, the throughput path.  One workgroup per polynomial
+//      pair; coefficients live in VGPRs (2^LPT per thread), the log2(n) radix-2
+//      stages run as ceil(log2 n / LPT) register phases with padded LDS
+//      transposes between them; psi-twist and n^-1 folded into the twiddles
+//      (fused_core.h).  HBM traffic per product = read a, read b, write c.
+//  cg_kernel            : K1-K5/K7, the reference's own constant-geometry
+//      dataflow (cg_ntt.py:49-64) held in LDS ping-pong buffers, canonical
+//      arithmetic at every step so each stage's output equals the reference's
+//      list `A` (trace parity); GROUP = butterflies issued per lane-step
+//      (8 = cg_ntt_8butterfly.py), PAD = conflict-free LDS image.
+//  fill_lcg_kernel / checksum_kernel : the reference benchmark's input
+//      generator and digest (benchmark_ntt_60bit.cpp:79-87,182-188), on device.
+#include <hip/hip_runtime.h>
+#include "plan.h"
+
+namespace tn {
+
+// ============================================================================
+// Fused kernel
+// ============================================================================
+template <typename E, typename Cfg, typename Pol>
+__device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
+                                            const Arith<E>& ar, E* lds) {
+  static_for<0, Cfg::PHASES>([&](auto p_) {
+    constexpr int p = decltype(p_)::value;
+    fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    if constexpr (p + 1 < Cfg::PHASES) {
+      ex_store<E, Cfg, p, p>(x, tau, lds);
+      __syncthreads();
+      ex_load<E, Cfg, p, p + 1>(x, tau, lds);
+      __syncthreads();
+    }
+  });
+}
+
+template <typename E, typename Cfg, typename Pol>
+__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
+                                            const Arith<E>& ar, E* lds) {
+  static_for<0, Cfg::PHASES>([&](auto i_) {
+    constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
+    inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    if constexpr (p > 0) {
+      ex_store<E, Cfg, p - 1, p>(x, tau, lds);
+      __syncthreads();
+      ex_load<E, Cfg, p - 1, p - 1>(x, tau, lds);
+      __syncthreads();
+    }
+  });
+}
+
+template <typename E, int LOGN, int LPT, bool LAZY>
+__global__ void __launch_bounds__((1 << (LOGN - LPT)))
+polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ c, u32 batch) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  typedef Policy<E, LAZY> Pol;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  E* lds = reinterpret_cast<E*>(tn_smem);
+  const u32 tau = threadIdx.x;
+  const Arith<E> ar = pv.ar;
+  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
+    const size_t off = (size_t)row << LOGN;
+    E xa[Cfg::R], xb[Cfg::R];
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(a[off + Cfg::jidx(0, tau, r)], ar);
+    forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, ar, lds);
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(b[off + Cfg::jidx(0, tau, r)], ar);
+    forward_all<E, Cfg, Pol>(xb, tau, pv.psi_brv, ar, lds);
+    pointwise<E, Cfg, Pol>(xa, xb, ar);
+    inverse_all<E, Cfg, Pol>(xa, tau, pv.psi_inv_brv, ar, lds);
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) c[off + Cfg::jidx(0, tau, r)] = xa[r];
+  }
+}
+
+// log2(n) -> coefficients per thread (log2)
+static int fused_lpt(u32 logn) {
+  switch (logn) {
+    case 8: return 2;
+    case 10: return 4;
+    case 12: return 4;
+    default: return 0;
+  }
+}
+
+bool fused_supported(u32 logn, int) { return fused_lpt(logn) != 0; }
+
+template <typename E, int LOGN, int LPT, bool LAZY>
+static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E);
+  auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  const u32 grid = (u32)(batch < (size_t)1 << 20 ? batch : (size_t)1 << 20);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, make_view<E>(p), (const E*)a, (const E*)b, (E*)c, (u32)batch);
+  return hipGetLastError();
+}
+
+template <typename E, bool LAZY>
+static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  switch (p->logn) {
+    case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s);
+    case 10: return launch_fused_t<E, 10, 4, LAZY>(p, a, b, c, batch, s);
+    case 12: return launch_fused_t<E, 12, 4, LAZY>(p, a, b, c, batch, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  if (p->elem_bytes == 8)
+    return p->lazy ? launch_fused_e<u64, true>(p, a, b, c, batch, s) : launch_fused_e<u64, false>(p, a, b, c, batch, s);
+  return p->lazy ? launch_fused_e<u32, true>(p, a, b, c, batch, s) : launch_fused_e<u32, false>(p, a, b, c, batch, s);
+}
+
+const char* fused_kernel_name(const tn_plan* p) {
+  (void)p;
+  return "polymul_fused_kernel";
+}
+
+// ============================================================================
+// Constant-geometry kernel (reference dataflow, canonical arithmetic)
+// ============================================================================
+template <typename E, int GROUP, bool PAD> struct CgMap {
+  // LDS element address of logical index x.  PAD inserts 16 bytes after every
+  // 2*GROUP elements (one lane-step's contiguous read), which makes the
+  // lane-strided 2*GROUP-element reads bank-conflict free.
+  static constexpr u32 CH = 2 * GROUP, PADE = 16 / sizeof(E);
+  __device__ __forceinline__ static u32 at(u32 x) { return PAD ? x + (x / CH) * PADE : x; }
+  __host__ __device__ static constexpr u32 span(u32 n) { return PAD ? n + (n / CH) * PADE : n; }
+};
+
+// One CG transform in LDS: src holds the bit-reversed input; log2(n) stages
+// ping-pong between src and dst; returns the buffer holding the natural-order
+// result.  (cg_ntt.py:49-64.)  If trace != nullptr every stage's output is
+// also written there ([logn][n]).
+template <typename E, int GROUP, bool PAD>
+__device__ E* cg_stages(E* src, E* dst, const typename TwOf<E>::type* __restrict__ omega_tab, u32 n, u32 logn,
+                        const Arith<E>& ar, E* trace) {
+  typedef CgMap<E, GROUP, PAD> M;
+  const u32 pairs = n >> 1;
+  for (u32 stage = 1; stage <= logn; ++stage) {
+    const u32 k = n >> stage;                                      // cg_ntt.py:50
+    for (u32 i0 = threadIdx.x * GROUP; i0 < pairs; i0 += blockDim.x * GROUP) {
+      E left[GROUP], right[GROUP];
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {                            // :55-56 (8 at a time: cg_ntt_8butterfly.py:70-77)
+        const bool live = (GROUP == 1) || (i0 + g < pairs);
+        left[g] = live ? src[M::at(2 * (i0 + g))] : (E)0;          // pad lanes read as (0, 0): cg_ntt_8butterfly.py:79-83
+        right[g] = live ? src[M::at(2 * (i0 + g) + 1)] : (E)0;
+      }
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const u32 i = i0 + g;
+        if (GROUP > 1 && i >= pairs) break;                        // pad lanes (cg_ntt_8butterfly.py:79-83): nothing stored
+        const typename TwOf<E>::type w = omega_tab[i & ~(k - 1)];  // omega_s^(i//k) = omega^(k*(i//k))  (:51,:54)
+        const E t = mul_tw(right[g], w, ar.q);                     // :57
+        const E s = left[g] + t;
+        dst[M::at(i)] = csub(s, ar.q);                             // :58
+        dst[M::at(i + pairs)] = left[g] >= t ? left[g] - t : left[g] + (ar.q - t);   // :59
+      }
+    }
+    __syncthreads();
+    if (trace) {
+      for (u32 i = threadIdx.x; i < n; i += blockDim.x) trace[(size_t)(stage - 1) * n + i] = dst[M::at(i)];
+    }
+    E* t = src; src = dst; dst = t;                                // :63-64
+  }
+  return src;
+}
+
+// bit_reverse_list on load (cg_ntt.py:21-26,:39): reordered[rev(idx)] = f(values[idx]);
+// coalesced global read, scattered LDS write.  tw == nullptr: plain reduction mod q.
+template <typename E, int GROUP, bool PAD>
+__device__ void cg_load_brv(E* buf, const E* __restrict__ in, const typename TwOf<E>::type* __restrict__ tw, u32 n, u32 logn,
+                            const Arith<E>& ar) {
+  typedef CgMap<E, GROUP, PAD> M;
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    const E v = tw ? mul_tw(in[i], tw[i], ar.q) : mul_tw(in[i], ar.one, ar.q);   // twist :82-83 / implicit % of :55-58
+    buf[M::at(__brev(i) >> (32 - logn))] = v;
+  }
+  __syncthreads();
+}
+
+template <typename E, int GROUP, bool PAD>
+__global__ void __launch_bounds__(256)
+cg_kernel(PlanView<E> pv, int mode, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* trace, u32 batch) {
+  typedef CgMap<E, GROUP, PAD> M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  const u32 n = pv.n, logn = pv.logn;
+  const u32 span = (M::span(n) + 3u) & ~3u;
+  E* p0 = reinterpret_cast<E*>(tn_smem);
+  E* p1 = p0 + span;
+  E* p2 = p1 + span;
+  const Arith<E> ar = pv.ar;
+  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
+    const size_t off = (size_t)row * n;
+    E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
+    if (mode == CG_NTT_FWD || mode == CG_TWIST_FWD) {
+      cg_load_brv<E, GROUP, PAD>(p0, a + off, mode == CG_TWIST_FWD ? pv.psi_pow : nullptr, n, logn, ar);
+      E* r = cg_stages<E, GROUP, PAD>(p0, p1, pv.omega_pow, n, logn, ar, tr);
+      for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[off + i] = r[M::at(i)];
+    } else if (mode == CG_NTT_INV) {                               // cg_intt: cg_ntt.py:68-75
+      cg_load_brv<E, GROUP, PAD>(p0, a + off, nullptr, n, logn, ar);
+      E* r = cg_stages<E, GROUP, PAD>(p0, p1, pv.omega_inv_pow, n, logn, ar, nullptr);
+      for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[off + i] = mul_tw(r[M::at(i)], ar.ninv, ar.q);   // :74-75
+    } else {                                                       // nwc_poly_mult: cg_ntt.py:78-92
+      cg_load_brv<E, GROUP, PAD>(p0, a + off, pv.psi_pow, n, logn, ar);                 // :82
+      E* ra = cg_stages<E, GROUP, PAD>(p0, p1, pv.omega_pow, n, logn, ar, nullptr);     // :86
+      E* f1 = (ra == p0) ? p1 : p0;
+      cg_load_brv<E, GROUP, PAD>(p2, b + off, pv.psi_pow, n, logn, ar);                 // :83
+      E* rb = cg_stages<E, GROUP, PAD>(p2, f1, pv.omega_pow, n, logn, ar, nullptr);     // :87
+      E* f2 = (rb == p2) ? f1 : p2;
+      for (u32 i = threadIdx.x; i < n; i += blockDim.x)                                 // :88, stored bit-reversed for :73
+        f2[M::at(__brev(i) >> (32 - logn))] = mulmod_barrett(ra[M::at(i)], rb[M::at(i)], ar.q, ar.mu, ar.k);
+      __syncthreads();
+      E* rc = cg_stages<E, GROUP, PAD>(f2, ra, pv.omega_inv_pow, n, logn, ar, nullptr); // :90 (:72-73)
+      for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+        out[off + i] = mul_tw(rc[M::at(i)], pv.psi_inv_ninv[i], ar.q);                  // :74-75 and :91-92 in one exact product
+    }
+    __syncthreads();
+  }
+}
+
+template <typename E, int GROUP, bool PAD>
+static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
+                              hipStream_t s) {
+  typedef CgMap<E, GROUP, PAD> M;
+  const u32 span = (M::span(p->n) + 3u) & ~3u;
+  const size_t lds_bytes = (size_t)3 * span * sizeof(E);
+  auto kern = cg_kernel<E, GROUP, PAD>;
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  u32 threads = (p->n / 2 + GROUP - 1) / GROUP;
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+  const u32 grid = (u32)(batch < (size_t)1 << 20 ? batch : (size_t)1 << 20);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, make_view<E>(p), mode, (const E*)a, (const E*)b, (E*)out,
+                     (E*)trace, (u32)batch);
+  return hipGetLastError();
+}
+
+template <typename E>
+static hipError_t launch_cg_e(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
+                              void* trace, size_t batch, hipStream_t s) {
+  if (group == 1) return launch_cg_t<E, 1, false>(p, mode, a, b, out, trace, batch, s);
+  if (group == 2) return padded ? launch_cg_t<E, 2, true>(p, mode, a, b, out, trace, batch, s)
+                                : launch_cg_t<E, 2, false>(p, mode, a, b, out, trace, batch, s);
+  if (group == 4) return padded ? launch_cg_t<E, 4, true>(p, mode, a, b, out, trace, batch, s)
+                                : launch_cg_t<E, 4, false>(p, mode, a, b, out, trace, batch, s);
+  if (group == 8) return padded ? launch_cg_t<E, 8, true>(p, mode, a, b, out, trace, batch, s)
+                                : launch_cg_t<E, 8, false>(p, mode, a, b, out, trace, batch, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out, void* trace,
+                     size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  if (p->elem_bytes == 8) return launch_cg_e<u64>(p, mode, group, padded, a, b, out, trace, batch, s);
+  return launch_cg_e<u32>(p, mode, group, padded, a, b, out, trace, batch, s);
+}
+
+const char* cg_kernel_name(const tn_plan*, int, bool) { return "cg_kernel"; }
+
+// ============================================================================
+// Synthetic inputs + digest (reference benchmark conventions)
+// ============================================================================
+static constexpr u64 LCG_A = 6364136223846793005ULL, LCG_C = 1442695040888963407ULL;
+
+template <typename E>
+__global__ void fill_lcg_kernel(E* __restrict__ dst, u32 n, u64 q, int narrow, u64 seed0, u64 stride, u32 batch) {
+  const u32 CH = n < 16 ? n : 16;
+  const u32 chunks = n / CH;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)batch * chunks) return;
+  const u32 row = (u32)(gid / chunks), i0 = (u32)(gid % chunks) * CH;
+  // x_i0 = f^i0(seed), f(x) = A x + C mod 2^64: square-and-multiply on affine maps
+  u64 ra = 1, rc = 0, ba = LCG_A, bc = LCG_C;
+  for (u32 e = i0; e; e >>= 1) {
+    if (e & 1) { rc = ba * rc + bc; ra = ba * ra; }
+    bc = ba * bc + bc; ba = ba * ba;
+  }
+  u64 x = ra * (seed0 + (u64)row * stride) + rc;
+  for (u32 i = 0; i < CH; ++i) {
+    x = LCG_A * x + LCG_C;                                         // benchmark_ntt_60bit.cpp:83
+    dst[(size_t)row * n + i0 + i] = (E)(narrow ? (x >> 17) % q : x % q);   // :84 / benchmark_ntt.cpp:87
+  }
+}
+
+template <typename E>
+__global__ void checksum_kernel(const E* __restrict__ src, u64* __restrict__ out, u32 n, int narrow, u32 batch) {
+  const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= batch) return;
+  const u64 M = 0xffffffffffffffc5ULL;
+  u64 acc = 0;
+  for (u32 i = 0; i < n; ++i) {
+    const u64 v = src[(size_t)row * n + i];
+    if (narrow) {
+      acc = (acc * 1315423911ULL + v) % M;                          // benchmark_ntt.cpp:228-233 (wraps mod 2^64 first)
+    } else {
+      // (acc*K + v) mod M with a 128-bit intermediate (benchmark_ntt_60bit.cpp:182-188); M = 2^64 - 59
+      u64 lo = acc * 1315423911ULL, hi = mulhi64(acc, 1315423911ULL);
+      const u64 lo2 = lo + v;
+      hi += (lo2 < lo);
+      u64 r = lo2 + hi * 59;                                        // 2^64 == 59 (mod M); hi < 2^31
+      if (r < lo2) r += 59;
+      acc = r >= M ? r - M : r;
+    }
+  }
+  out[row] = acc;
+}
+
+hipError_t launch_fill_lcg(const tn_plan* p, void* dst, size_t batch, u64 seed0, u64 stride, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  const u32 CH = p->n < 16 ? p->n : 16;
+  const size_t total = batch * (p->n / CH);
+  const u32 blocks = (u32)((total + 255) / 256);
+  const int narrow = p->q < ((u64)1 << 32);
+  if (p->elem_bytes == 8)
+    hipLaunchKernelGGL(fill_lcg_kernel<u64>, dim3(blocks), dim3(256), 0, s, (u64*)dst, p->n, p->q, narrow, seed0, stride, (u32)batch);
+  else
+    hipLaunchKernelGGL(fill_lcg_kernel<u32>, dim3(blocks), dim3(256), 0, s, (u32*)dst, p->n, p->q, narrow, seed0, stride, (u32)batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_checksum(const tn_plan* p, const void* src, u64* out, size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  const u32 blocks = (u32)((batch + 63) / 64);
+  const int narrow = p->q < ((u64)1 << 32);
+  if (p->elem_bytes == 8)
+    hipLaunchKernelGGL(checksum_kernel<u64>, dim3(blocks), dim3(64), 0, s, (const u64*)src, out, p->n, narrow, (u32)batch);
+  else
+    hipLaunchKernelGGL(checksum_kernel<u32>, dim3(blocks), dim3(64), 0, s, (const u32*)src, out, p->n, narrow, (u32)batch);
+  return hipGetLastError();
+}
+
+}  // namespace tn

@@ -1,0 +1,162 @@
+// modarith.h — exact modular arithmetic shared by the HIP kernels (device) and
+// the plan builder / CPU emulation of the kernels (host).  Pure integer code.
+//
+// Reduction family: Barrett.  Three forms are used, all exact (bit-identical to
+// the `%` the reference uses: new_reference/cg_ntt.py:57-59, :75, :88, :92;
+// software_benchmark/benchmark_ntt_60bit.cpp:75-77):
+//
+//  * mul_tw_*   — Barrett with the quotient factor precomputed PER CONSTANT
+//                 (twiddle w carries wp = floor(w * 2^W / q), W = word bits).
+//                 This is the butterfly multiply: every twiddle, twist factor
+//                 and scale factor is a plan-time constant.
+//  * mulmod_barrett* — classic two-operand Barrett with mu = floor(2^(2k)/q),
+//                 k = bitlen(q): q1 = p >> (k-1); q2 = (q1*mu) >> (k+1);
+//                 r = p - q2*q; conditional subtracts.  The recipe of
+//                 scripts/precompute_constants.py:38-46 and
+//                 rtl/barrett_reduction.v:23-29; used for the pointwise product
+//                 where both operands are data.
+//  * fold_*     — for moduli just below a power of two (q = 2^k - c, c small;
+//                 both reference moduli are: 2^23-2^13+1, 2^60-2^14+1) one
+//                 Barrett step with the quotient estimate x >> k:
+//                 x - (x>>k)*q = (x mod 2^k) + (x>>k)*c.  Keeps lazy values bounded.
+//
+// gfx950 cost model (tools/ubench/valu_rates.hip, measured): v_mad_u64_u32,
+// v_mul_lo/hi_u32, v_add_co/addc, v_add3, v_alignbit are all one 4-cycle issue
+// slot per wave; only v_and/or/xor/add_u32/sub_u32/lshrrev/mov/cndmask are
+// 2-cycle.  So a 32x32+64 multiply-add costs the same as a carry add, and the
+// formulations below are mad-heavy on purpose.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TN_HD __host__ __device__ __forceinline__
+#else
+#define TN_HD inline
+#endif
+
+namespace tn {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ----------------------------------------------------------------------------
+// Twiddle records: the constant and its precomputed Barrett quotient factor.
+struct Tw64 { u64 w, wp; };   // wp = floor(w * 2^64 / q)
+struct Tw32 { u32 w, wp; };   // wp = floor(w * 2^32 / q)
+
+template <typename E> struct TwOf;
+template <> struct TwOf<u64> { typedef Tw64 type; };
+template <> struct TwOf<u32> { typedef Tw32 type; };
+
+// 64x64 -> high 64.  Device: __umul64hi (4 v_mad_u64_u32); host: __int128.
+TN_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// >= floor(a*wp / 2^64) - 1, never above it: drops the a0*wp0 partial product
+// (worth < 1) but carries the middle sum exactly.  3 mads + carry fix-up.
+TN_HD u64 mulhi64_lo1(u64 a, u64 wp) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+  u64 m = (u64)a0 * p1;
+  u64 t = (u64)a1 * p0;
+  m += t;
+  u64 c = (m < t) ? ((u64)1 << 32) : 0;
+  return (u64)a1 * p1 + (m >> 32) + c;
+}
+
+// ---- 64-bit lanes -----------------------------------------------------------
+// a: ANY u64;  result == a*w (mod q), in [0, 3q).  Needs 3q < 2^64.
+TN_HD u64 mul_tw_lazy(u64 a, Tw64 t, u64 q) {
+  u64 qh = mulhi64_lo1(a, t.wp);      // in {Q-2, Q-1, Q}, Q = floor(a*w/q)
+  return a * t.w - qh * q;            // wraps mod 2^64; true value < 3q
+}
+
+TN_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+
+// canonical [0,q)
+TN_HD u64 mul_tw(u64 a, Tw64 t, u64 q) {
+  u64 r = mul_tw_lazy(a, t, q);
+  r = csub(r, q);
+  return csub(r, q);
+}
+
+// Two-operand Barrett (A9).  a, b in [0, q); k = bitlen(q) in [2, 62]; mu = floor(2^(2k)/q) (<= k+1 bits).
+TN_HD u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu, int k) {
+  u64 plo = a * b, phi = mulhi64(a, b);                       // p < 2^(2k)
+  u64 q1 = (k - 1 == 0) ? plo : ((phi << (64 - (k - 1))) | (plo >> (k - 1)));   // p >> (k-1), <= k+1 bits
+  u64 mlo = q1 * mu, mhi = mulhi64(q1, mu);                   // q1*mu < 2^(2k+2)
+  u64 q2 = (mhi << (64 - (k + 1))) | (mlo >> (k + 1));        // >> (k+1)
+  u64 r = plo - q2 * q;                                       // true value in [0, 3q)
+  r = csub(r, q);
+  return csub(r, q);                                          // second subtract kept: single-subtract bound unproven
+}
+
+// One Barrett step with quotient estimate x >> k, for q = 2^k - c:  result == x (mod q),
+// < 2^k + (x >> k) * c.
+TN_HD u64 fold(u64 x, int k, u32 c) {
+  u64 lowmask = (((u64)1) << k) - 1;
+  return (x & lowmask) + (u64)(u32)(x >> k) * c;              // one v_mad_u64_u32 on device
+}
+
+// ---- 32-bit lanes -----------------------------------------------------------
+// a: ANY u32; result == a*w (mod q) in [0, 2q).  Needs 2q < 2^32.
+TN_HD u32 mul_tw_lazy(u32 a, Tw32 t, u32 q) {
+  u32 qh = (u32)(((u64)a * t.wp) >> 32);                      // exact high half: in {Q-1, Q}
+  return a * t.w - qh * q;
+}
+
+TN_HD u32 csub(u32 x, u32 q) { return x >= q ? x - q : x; }
+
+TN_HD u32 mul_tw(u32 a, Tw32 t, u32 q) { return csub(mul_tw_lazy(a, t, q), q); }
+
+// a, b in [0,q), k = bitlen(q) <= 31, mu = floor(2^(2k)/q) (<= k+1 bits <= 32)
+TN_HD u32 mulmod_barrett(u32 a, u32 b, u32 q, u64 mu, int k) {
+  u64 p = (u64)a * b;
+  u64 q1 = p >> (k - 1);
+  u64 q2 = (q1 * mu) >> (k + 1);                              // q1, mu <= 32 bits: product fits 64
+  u32 r = (u32)p - (u32)q2 * q;
+  r = csub(r, q);
+  return csub(r, q);
+}
+
+TN_HD u32 fold(u32 x, int k, u32 c) {
+  u32 lowmask = (((u32)1) << k) - 1;
+  return (x & lowmask) + (x >> k) * c;
+}
+
+// ---- host-side helpers (plan building; exact, slow path is fine) -------------
+inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); }
+inline u64 h_powmod(u64 b, u64 e, u64 q) {
+  u64 r = 1 % q; b %= q;
+  while (e) { if (e & 1) r = h_mulmod(r, b, q); b = h_mulmod(b, b, q); e >>= 1; }
+  return r;
+}
+inline int h_bitlen(u64 x) { int n = 0; while (x) { ++n; x >>= 1; } return n; }
+inline Tw64 h_make_tw64(u64 w, u64 q) {
+  Tw64 t; t.w = w; t.wp = (u64)((((unsigned __int128)w) << 64) / q); return t;
+}
+inline Tw32 h_make_tw32(u64 w, u64 q) {
+  Tw32 t; t.w = (u32)w; t.wp = (u32)((w << 32) / q); return t;
+}
+// deterministic Miller-Rabin for 64-bit (bases cover all n < 2^64)
+inline bool h_is_prime(u64 n) {
+  if (n < 2) return false;
+  static const u64 small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  for (u64 p : small) { if (n == p) return true; if (n % p == 0) return false; }
+  u64 d = n - 1; int s = 0;
+  while ((d & 1) == 0) { d >>= 1; ++s; }
+  for (u64 a : small) {
+    u64 x = h_powmod(a, d, n);
+    if (x == 1 || x == n - 1) continue;
+    bool comp = true;
+    for (int i = 1; i < s; ++i) { x = h_mulmod(x, x, n); if (x == n - 1) { comp = false; break; } }
+    if (comp) return false;
+  }
+  return true;
+}
+
+}  // namespace tn

@@ -1,0 +1,72 @@
+// plan.h — internal plan object behind the opaque tn_plan handle, and the
+// kernel launch entry points implemented in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "fused_core.h"
+
+struct tn_plan {
+  tn::u32 n = 0, logn = 0;
+  tn::u64 q = 0, psi = 0, omega = 0;
+  int device = 0;
+  tn::u32 flags = 0;
+  int elem_bytes = 8;
+  bool has_fused = false, lazy = false;
+  int k = 0;            // bitlen(q)
+  tn::u64 mu = 0;       // floor(2^(2k)/q)
+  tn::u32 fold_c = 0;   // 2^k - q when lazy
+  tn::u64 one_w = 1, one_wp = 0, ninv_w = 0, ninv_wp = 0, ninv_w1_w = 0, ninv_w1_wp = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // device tables (Tw32[] or Tw64[] according to elem_bytes)
+  void* d_psi_brv = nullptr;       // [n]   psi^brv(i): merged forward twiddles (fused kernel)
+  void* d_psi_inv_brv = nullptr;   // [n]   psi^-brv(i)
+  void* d_omega_pow = nullptr;     // [n/2] omega^j   (cg_ntt.py:51,54 — pow(omega_s, i//k) = omega^(k*(i//k)))
+  void* d_omega_inv_pow = nullptr; // [n/2] omega^-j
+  void* d_psi_pow = nullptr;       // [n]   psi^i     (twist, cg_ntt.py:82-83)
+  void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
+  void* d_scratch = nullptr;       // host-entry staging (grown on demand)
+  size_t scratch_bytes = 0;
+};
+
+namespace tn {
+
+enum CgMode { CG_NTT_FWD = 0, CG_NTT_INV = 1, CG_POLYMUL = 2, CG_TWIST_FWD = 3 };
+
+template <typename E> struct PlanView {
+  typedef typename TwOf<E>::type Tw;
+  u32 n, logn;
+  Arith<E> ar;
+  const Tw* psi_brv;
+  const Tw* psi_inv_brv;
+  const Tw* omega_pow;
+  const Tw* omega_inv_pow;
+  const Tw* psi_pow;
+  const Tw* psi_inv_ninv;
+};
+
+template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
+  typedef typename TwOf<E>::type Tw;
+  PlanView<E> v;
+  v.n = p->n; v.logn = p->logn;
+  v.ar.q = (E)p->q; v.ar.mu = p->mu; v.ar.k = p->k; v.ar.fold_c = p->fold_c;
+  v.ar.one.w = (E)p->one_w; v.ar.one.wp = (E)p->one_wp;
+  v.ar.ninv.w = (E)p->ninv_w; v.ar.ninv.wp = (E)p->ninv_wp;
+  v.ar.ninv_w1.w = (E)p->ninv_w1_w; v.ar.ninv_w1.wp = (E)p->ninv_w1_wp;
+  v.psi_brv = (const Tw*)p->d_psi_brv; v.psi_inv_brv = (const Tw*)p->d_psi_inv_brv;
+  v.omega_pow = (const Tw*)p->d_omega_pow; v.omega_inv_pow = (const Tw*)p->d_omega_inv_pow;
+  v.psi_pow = (const Tw*)p->d_psi_pow; v.psi_inv_ninv = (const Tw*)p->d_psi_inv_ninv;
+  return v;
+}
+
+// kernels.hip
+bool fused_supported(u32 logn, int elem_bytes);
+const char* fused_kernel_name(const tn_plan* p);
+const char* cg_kernel_name(const tn_plan* p, int group, bool padded);
+hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
+hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
+                     void* trace, size_t batch, hipStream_t s);
+hipError_t launch_fill_lcg(const tn_plan* p, void* dst, size_t batch, u64 seed0, u64 stride, hipStream_t s);
+hipError_t launch_checksum(const tn_plan* p, const void* src, u64* out, size_t batch, hipStream_t s);
+
+}  // namespace tn
