@@ -20,8 +20,8 @@
  *   - Inputs need not be reduced: any word value is taken mod q, as the
  *     reference's `%` does (cg_ntt.py:82-83).
  *   - *_dev entry points take DEVICE pointers (hipMalloc / torch tensors) and a
- *     hipStream_t passed as void* (NULL = the plan's own stream); they enqueue
- *     and return.  *_host entry points take host pointers, copy in, run, copy
+ *     hipStream_t passed as void* (NULL = the plan's own stream; TN_STREAM_LEGACY =
+ *     the device's legacy default stream, hipStreamLegacy); they enqueue and return.  *_host entry points take host pointers, copy in, run, copy
  *     out and synchronise.
  *   - a, b are read-only; c must not alias a or b.
  *   - Every function returns a tn_status; nothing throws or aborts across the
@@ -41,6 +41,7 @@ extern "C" {
 #endif
 
 #define TN_VERSION 100 /* 0.1.0 */
+#define TN_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the stream handle-0 callers (e.g. torch's default stream) mean */
 
 typedef enum tn_status {
   TN_OK = 0,

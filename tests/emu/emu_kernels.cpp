@@ -54,8 +54,22 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
         xa[tau].x[r] = Pol::load((E)a[off + Cfg::jidx(0, tau, r)], ar);
         xb[tau].x[r] = Pol::load((E)b[off + Cfg::jidx(0, tau, r)], ar);
       }
-    forward(xa);
-    forward(xb);
+    if (row & 1) {            // odd rows: the kernel's pair schedule; even rows: one operand at a time
+      static_for<0, Cfg::PHASES>([&](auto p_) {
+        constexpr int p = decltype(p_)::value;
+        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
+          fwd_phase_pair<E, Cfg, Pol, p>(xa[tau].x, xb[tau].x, tau, psi_brv.data(), ar);
+        if constexpr (p + 1 < Cfg::PHASES) {
+          for (auto* x : {&xa, &xb}) {
+            for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p, p>((*x)[tau].x, tau, lds.data());
+            for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_load<E, Cfg, p, p + 1>((*x)[tau].x, tau, lds.data());
+          }
+        }
+      });
+    } else {
+      forward(xa);
+      forward(xb);
+    }
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) pointwise<E, Cfg, Pol>(xa[tau].x, xb[tau].x, ar);
     inverse(xa);
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
@@ -69,7 +83,7 @@ int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size
   switch (t.logn) {
     case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch);
     case 10: return fused_polymul_emu<E, 10, 4, LAZY>(t, a, b, c, batch);
-    case 12: return fused_polymul_emu<E, 12, 4, LAZY>(t, a, b, c, batch);
+    case 12: return fused_polymul_emu<E, 12, 3, LAZY>(t, a, b, c, batch);
     default: return 7;
   }
 }

@@ -1,0 +1,310 @@
+"""GPU parity tests proper (run with -m gpu on the MI355X box).  Everything goes through the
+C ABI (libtinyntt.so via tiny_ntt_amd.engine); results must be bit-exact against the committed
+golden vectors (made by the reference's cg_ntt.py), against the oracle on seeded inputs, and —
+at BASELINE.json's full sizes — satisfy size-independent properties (reference checksums,
+linearity, commutativity, identity, wrap-around)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import PARAMS, REF_CHECKSUMS
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ["P4", "P256", "P1024", "P4096", "P4096_60"]
+ALL_VARIANTS = ["fused", "cg", "cg8", "cg8_padded"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from tiny_ntt_amd import engine
+    lib = engine.load_library()
+    assert engine.LIB_PATH.endswith("tiny_ntt_amd/lib/libtinyntt.so") and lib is not None
+    return engine
+
+
+def plan_for(eng, tag, flags=0):
+    return eng.get_plan(*PARAMS[tag], 0, flags)
+
+
+def variants_of(plan):
+    return [v for v in ALL_VARIANTS if v != "fused" or plan.has_fused]
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("tag", TAGS)
+def test_poly_mult_matches_reference_golden(eng, golden, tag):
+    g, plan = golden(tag), plan_for(eng, tag)
+    for name in g.cases("poly_mult"):
+        a, b, c = g[name + "_a"], g[name + "_b"], g[name + "_c"]
+        for v in variants_of(plan):
+            got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v)
+            assert got.dtype == plan.dtype and np.array_equal(got.astype(np.uint64), c), f"{tag} {name} {v}"
+
+
+@pytest.mark.parametrize("tag", ["P256", "P1024", "P4096", "P4096_60"])
+def test_fused_canonical_policy_matches_golden(eng, golden, tag):
+    g = golden(tag)
+    plan = plan_for(eng, tag, eng.PLAN_FORCE_CANONICAL)
+    assert plan.has_fused and not plan.is_lazy
+    assert plan_for(eng, tag).is_lazy
+    for name in g.cases("poly_mult"):
+        got = plan.poly_mult(g[name + "_a"].astype(plan.dtype), g[name + "_b"].astype(plan.dtype), variant="fused")
+        assert np.array_equal(got.astype(np.uint64), g[name + "_c"]), name
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_transforms_and_stage_traces_match_reference_golden(eng, golden, tag):
+    g, plan = golden(tag), plan_for(eng, tag)
+    assert plan.omega == g.omega
+    w = min(16, g.n)
+    for name in g.cases("ntt"):
+        x, X = g[name + "_x"], g[name + "_X"]
+        for v in ("cg", "cg8", "cg8_padded"):
+            assert np.array_equal(plan.ntt_forward(x.astype(plan.dtype), variant=v).astype(np.uint64), X), f"{name} {v}"
+            assert np.array_equal(plan.ntt_inverse(X.astype(plan.dtype), variant=v).astype(np.uint64), x % np.uint64(g.q)), f"{name} {v} inverse"
+            out, trace = plan.ntt_forward_trace(x.astype(plan.dtype), variant=v)
+            assert np.array_equal(out.astype(np.uint64), X)
+            assert np.array_equal(trace[:, :w].astype(np.uint64), g[name + "_trace16"]), f"{name} {v} per-stage trace (cg_ntt.py:60-62)"
+    if tag != "P4":
+        fwd = plan.twisted_ntt_forward(g["lcg12_mul_a"].astype(plan.dtype))
+        assert np.array_equal(fwd.astype(np.uint64), g["lcg1_fwd"])
+
+
+# ---------------------------------------------------------------- seeded random vs the oracle
+@pytest.mark.parametrize("tag", TAGS)
+def test_random_batches_vs_oracle_incl_unreduced_inputs(eng, oracle, tag):
+    n, q, psi = PARAMS[tag]
+    plan = plan_for(eng, tag)
+    rng = np.random.default_rng(1234)
+    B = 64
+    word = 2 ** (8 * plan.elem_bytes) - 1
+    a = rng.integers(0, q, (B, n), dtype=np.uint64); b = rng.integers(0, q, (B, n), dtype=np.uint64)
+    a[0], b[0] = q - 1, q - 1
+    a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b[1] = word     # any word is taken mod q
+    a[2], b[2] = word, word
+    a[3] = 0
+    ref = oracle.poly_mult(a, b, q, psi)
+    for v in variants_of(plan):
+        got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
+        assert np.array_equal(got, ref), f"{tag} {v}: {np.count_nonzero(got != ref)} coefficients differ"
+    A = plan.ntt_forward(a.astype(plan.dtype)).astype(np.uint64)
+    for r in (0, 1, 5):
+        assert np.array_equal(A[r], oracle.cg_ntt(a[r], plan.omega, q))
+    assert np.array_equal(plan.ntt_inverse(A.astype(plan.dtype)).astype(np.uint64), a % np.uint64(q))
+
+
+def test_ragged_and_empty_batches(eng, oracle):
+    n, q, psi = PARAMS["P1024"]
+    plan = plan_for(eng, "P1024")
+    rng = np.random.default_rng(5)
+    for B in (1, 2, 3, 63, 65, 257):
+        a = rng.integers(0, q, (B, n), dtype=np.uint32); b = rng.integers(0, q, (B, n), dtype=np.uint32)
+        assert np.array_equal(plan.poly_mult(a, b).astype(np.uint64), oracle.poly_mult(a.astype(np.uint64), b.astype(np.uint64), q, psi))
+    empty = np.empty((0, n), dtype=np.uint32)
+    assert plan.poly_mult(empty, empty).shape == (0, n)
+    one = plan.poly_mult(a[0], b[0])
+    assert one.shape == (n,)
+    with pytest.raises(ValueError, match="Expected 1024 coefficients"):
+        plan.poly_mult(a[:, :100], b[:, :100])
+
+
+def test_generic_moduli_run_canonical(eng, oracle):
+    n = 256
+    for q in (754974721, 2305843009196916737, 7681 * 0 + 12289):
+        if (q - 1) % (2 * n):
+            continue
+        psi = next(pow(x, (q - 1) // (2 * n), q) for x in range(2, 300) if pow(pow(x, (q - 1) // (2 * n), q), n, q) == q - 1)
+        plan = eng.get_plan(n, q, psi)
+        rng = np.random.default_rng(q % 1000)
+        a = rng.integers(0, q, (5, n), dtype=np.uint64); b = rng.integers(0, q, (5, n), dtype=np.uint64)
+        a[0], b[0] = q - 1, q - 1
+        ref = oracle.poly_mult(a, b, q, psi)
+        for v in variants_of(plan):
+            assert np.array_equal(plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64), ref), (q, v)
+
+
+def test_sizes_without_a_fused_kernel_use_cg(eng, oracle):
+    for n in (8, 16, 64, 128, 512, 2048):
+        q = 8380417
+        if (q - 1) % (2 * n):
+            continue
+        psi = next(pow(x, (q - 1) // (2 * n), q) for x in range(2, 300) if pow(pow(x, (q - 1) // (2 * n), q), n, q) == q - 1)
+        plan = eng.get_plan(n, q, psi)
+        rng = np.random.default_rng(n)
+        a = rng.integers(0, q, (9, n), dtype=np.uint64); b = rng.integers(0, q, (9, n), dtype=np.uint64)
+        ref = oracle.poly_mult(a, b, q, psi)
+        for v in ["auto"] + variants_of(plan):
+            assert np.array_equal(plan.poly_mult(a.astype(np.uint32), b.astype(np.uint32), variant=v).astype(np.uint64), ref), (n, v)
+
+
+# ---------------------------------------------------------------- the reference's own tests, through the mirror modules
+def negacyclic_convolution(a, b, q):
+    n = len(a)
+    res = [0] * n
+    for i, ai in enumerate(a):
+        if not ai:
+            continue
+        for j, bj in enumerate(b):
+            k, t = i + j, ai * bj % q
+            if k >= n:
+                k, t = k - n, (-t) % q
+            res[k] = (res[k] + t) % q
+    return res
+
+
+@pytest.fixture()
+def mirror(eng):
+    import tiny_ntt_amd.cg_ntt as cg
+    import tiny_ntt_amd.cg_ntt_8butterfly as cg8
+    cg.N, cg.Q = 256, 8380417
+    yield cg, cg8
+    cg.N, cg.Q = 256, 8380417
+
+
+PSI_2N = 1239911
+
+
+def test_mirror_identity_like_reference(mirror):            # new_reference/test_cg_ntt.py:44-52, test_cg_ntt_8butterfly.py:49-57
+    cg, cg8 = mirror
+    omega = pow(PSI_2N, 2, cg.Q)
+    random.seed(0)
+    a = [random.randrange(cg.Q) for _ in range(cg.N)]
+    lines = []
+    t = cg.cg_ntt(a, omega, cg.Q, verbose=True, log_fn=lines.append)
+    assert cg.cg_intt(t, omega, cg.Q) == a
+    assert lines[0] == "CG NTT start" and sum(l.startswith("  stage_out(first 16)=") for l in lines) == 8
+    random.seed(2)
+    a = [random.randrange(cg.Q) for _ in range(cg.N)]
+    assert cg8.cg_intt_8butterfly(cg8.cg_ntt_8butterfly(a, omega, cg.Q), omega, cg.Q) == a
+    random.seed(3)                                          # test_cg_ntt_8butterfly.py:60-68
+    a = [random.randrange(cg.Q) for _ in range(cg.N)]
+    assert cg8.cg_ntt_8butterfly(a, omega, cg.Q) == cg.cg_ntt(a, omega, cg.Q)
+
+
+def test_mirror_verbose_log_equals_reference_log(mirror, golden):
+    cg, cg8 = mirror
+    g = golden("P256")
+    x = [int(v) for v in g["seed0_ntt_x"]]
+    for mod, fn in ((cg, cg.cg_ntt), (cg8, cg8.cg_ntt_8butterfly)):
+        lines = []
+        fn(x, g.omega, g.q, True, lines.append)
+        outs = [eval(l.split("=", 1)[1]) for l in lines if l.startswith("  stage_out(first 16)=")]
+        assert np.array_equal(np.array(outs, dtype=np.uint64), g["seed0_ntt_trace16"])
+        assert eval([l for l in lines if l.startswith("  bitrev(first 16)=")][0].split("=", 1)[1]) == [int(v) for v in g["seed0_ntt_bitrev16"]]
+
+
+def test_mirror_kats_and_random_like_reference(mirror):     # test_cg_ntt.py:55-103, test_cg_ntt_8butterfly.py:71-118
+    cg, cg8 = mirror
+    def sparse(v):
+        return v + [0] * (cg.N - len(v))
+    for a, b in ((sparse([1, 2, 3]), sparse([4, 5, 6])), (sparse([1, 2, 3]), sparse([5, 1]))):
+        expect = negacyclic_convolution(a, b, cg.Q)
+        assert cg.nwc_poly_mult(a, b, PSI_2N) == expect
+        assert cg8.nwc_poly_mult_8butterfly(a, b, PSI_2N) == expect
+    assert cg.nwc_poly_mult(sparse([1, 2, 3]), sparse([4, 5, 6]), PSI_2N)[:6] == [4, 13, 28, 27, 18, 0]
+    assert cg.nwc_poly_mult(sparse([1, 5, 1]), sparse([5, 1]), PSI_2N)[:5] == [5, 26, 10, 1, 0]     # test_ntt_inverse.py:273-275
+    random.seed(1)
+    a = [random.randrange(cg.Q) for _ in range(cg.N)]
+    b = [random.randrange(cg.Q) for _ in range(cg.N)]
+    assert cg.nwc_poly_mult(a, b, PSI_2N) == negacyclic_convolution(a, b, cg.Q)
+    random.seed(4)
+    a = [random.randrange(cg.Q) for _ in range(cg.N)]
+    b = [random.randrange(cg.Q) for _ in range(cg.N)]
+    assert cg8.nwc_poly_mult_8butterfly(a, b, PSI_2N) == cg.nwc_poly_mult(a, b, PSI_2N)
+    assert cg.nwc_poly_mult([-1] + [0] * 255, sparse([2]), PSI_2N)[0] == cg.Q - 2        # Python ints of any sign, reduced with %
+
+
+def test_mirror_60bit_parameter_override(mirror, golden):
+    cg, cg8 = mirror
+    g = golden("P4096_60")
+    cg.N, cg.Q = g.n, g.q
+    a, b = [int(v) for v in g["seed1_mul_a"]], [int(v) for v in g["seed1_mul_b"]]
+    c = cg.nwc_poly_mult(a, b, g.psi)
+    assert c[:3] == [736315498995752632, 3636685963993676, 530706514351249966]
+    assert c == [int(v) for v in g["seed1_mul_c"]]
+    assert cg8.nwc_poly_mult_8butterfly(a, b, g.psi) == c
+
+
+# ---------------------------------------------------------------- BASELINE configs at full size: properties
+def _full_size_properties(eng, oracle, tag, batch, check_rows):
+    import torch
+    n, q, psi = PARAMS[tag]
+    plan = plan_for(eng, tag)
+    a = plan.fill_lcg(batch, 1, 2)            # row r = make_poly(2r+1)
+    b = plan.fill_lcg(batch, 2, 2)            # row r = make_poly(2r+2)
+    c = plan.poly_mult(a, b)
+    ha, hb, hc = plan.to_host(a[:check_rows]), plan.to_host(b[:check_rows]), plan.to_host(c[:check_rows])
+    # device generator == the reference's make_poly; row 0 reproduces the reference benchmark's printed checksum
+    assert np.array_equal(ha[0].astype(np.uint64), oracle.make_poly(1, n, q)) and np.array_equal(hb[0].astype(np.uint64), oracle.make_poly(2, n, q))
+    assert np.array_equal(ha[5].astype(np.uint64), oracle.make_poly(11, n, q))
+    sums = plan.checksum_rows(c)
+    assert int(sums[0]) == REF_CHECKSUMS[tag][1]
+    fwd = plan.twisted_ntt_forward(a[:1])
+    assert int(plan.checksum_rows(fwd)[0]) == REF_CHECKSUMS[tag][0]
+    # sample rows incl. the last ones, full compare vs the oracle
+    rows = list(range(check_rows))
+    ref = oracle.poly_mult(ha.astype(np.uint64), hb.astype(np.uint64), q, psi)
+    assert np.array_equal(hc.astype(np.uint64), ref)
+    tail = slice(batch - 4, batch)
+    assert np.array_equal(plan.to_host(c[tail]).astype(np.uint64),
+                          oracle.poly_mult(plan.to_host(a[tail]).astype(np.uint64), plan.to_host(b[tail]).astype(np.uint64), q, psi))
+    # checksum kernel == reference checksum function on the sampled rows
+    for r in (0, 1, check_rows - 1):
+        assert int(sums[r]) == oracle.checksum(hc[r].astype(np.uint64), q)
+    # commutativity over the whole batch (checksum of checksums)
+    c2 = plan.poly_mult(b, a)
+    assert torch.equal(c, c2)
+    # identity: a * 1 = a mod q ; wrap-around: (a * x^(n-1)) * x = -a
+    ident = torch.zeros_like(a[:256]); ident[:, 0] = 1
+    assert torch.equal(plan.poly_mult(a[:256], ident), a[:256])
+    xm = torch.zeros_like(a[:256]); xm[:, n - 1] = 1
+    x1 = torch.zeros_like(a[:256]); x1[:, 1] = 1
+    neg = plan.to_host(plan.poly_mult(plan.poly_mult(a[:256], xm), x1)).astype(np.uint64)
+    assert np.array_equal(neg, (np.uint64(q) - plan.to_host(a[:256]).astype(np.uint64)) % np.uint64(q))
+    # linearity: (a + a') * b = a*b + a'*b  (mod q), elementwise modular add on the host for a sample
+    ap = plan.fill_lcg(256, 1001, 3)
+    s = (plan.to_host(a[:256]).astype(np.uint64) + plan.to_host(ap).astype(np.uint64)) % np.uint64(q)
+    lhs = plan.poly_mult(s.astype(plan.dtype), plan.to_host(b[:256]))
+    rhs = (plan.to_host(c[:256]).astype(np.uint64) + plan.to_host(plan.poly_mult(ap, b[:256])).astype(np.uint64)) % np.uint64(q)
+    assert np.array_equal(lhs.astype(np.uint64), rhs)
+    # variants agree on a slab
+    for v in ("cg", "cg8", "cg8_padded"):
+        assert torch.equal(plan.poly_mult(a[:512], b[:512], variant=v), c[:512]), v
+    # outputs canonical
+    assert int(plan.to_host(c).max()) < q
+
+
+def test_config2_n1024_24bit_batch4096(eng, oracle):
+    _full_size_properties(eng, oracle, "P1024", 4096, 256)
+
+
+def test_config3_n4096_60bit_batch65536(eng, oracle):
+    _full_size_properties(eng, oracle, "P4096_60", 65536, 256)
+
+
+def test_n4096_24bit_batch8192(eng, oracle):
+    _full_size_properties(eng, oracle, "P4096", 8192, 64)
+
+
+def test_device_buffers_streams_and_aliasing(eng):
+    import torch
+    plan = plan_for(eng, "P4096_60")
+    a = plan.fill_lcg(128, 1, 2); b = plan.fill_lcg(128, 2, 2)
+    plan.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c1 = plan.poly_mult(a, b, stream=s)
+    s.synchronize()
+    c2 = plan.poly_mult(a, b); plan.synchronize()
+    assert torch.equal(c1, c2)
+    with pytest.raises(eng.TinyNttError, match="alias"):
+        plan.poly_mult(a, b, out=a)
+    with pytest.raises(eng.TinyNttError):
+        plan.poly_mult(a.cpu(), b.cpu())
+    with pytest.raises(eng.TinyNttError, match="only the CG variants"):
+        plan.ntt_forward(a, variant="fused")
+    assert plan.kernel_name("fused") == "polymul_fused_kernel" and plan.kernel_name("cg8") == "cg_kernel"

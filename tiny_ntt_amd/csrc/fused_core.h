@@ -53,17 +53,47 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
   // LDS image used between phase e and e+1:  addr(j) = j + PAD * (j >> SH)   (in elements)
   static constexpr int ex_pad(int e) { return pos(e + 1) > 0 ? (1 << pos(e + 1)) : (int)(16 / sizeof(E)); }
   static constexpr int ex_sh(int e) { return pos(e + 1) > 0 ? pos(e + 1) + LPT : LPT; }
-  static constexpr int ex_elems(int e) { return N + ex_pad(e) * (N >> ex_sh(e)); }
+  static constexpr int lay_span(int e, int cnt) { return cnt + ex_pad(e) * (cnt >> ex_sh(e)); }
+  // Waves: thread-id bits >= 6.  WB of them; in every phase after the first they are the top
+  // WB bits of the coefficient index, so a wave owns one contiguous slice of 2^WSH coefficients.
+  static constexpr int WB = (LOGN - LPT > 6) ? (LOGN - LPT - 6) : 0;
+  static constexpr int WSH = LOGN - WB;
+  // j-bit position that thread-id bit t maps to in phase p
+  static constexpr int tau_bit_to_j(int p, int t) { return t < pos(p) ? t : t + LPT; }
+  // An exchange between phases e and e+1 stays inside each 64-lane wave iff in both phases the
+  // wave index is made of the top WB coefficient-index bits; then no workgroup barrier is needed
+  // (a wave's LDS operations execute in issue order) provided each wave uses a private LDS region.
+  static constexpr bool ex_wave_local(int e) {
+    for (int t = 6; t < LOGN - LPT; ++t)
+      if (tau_bit_to_j(e, t) != t + LPT || tau_bit_to_j(e + 1, t) != t + LPT) return false;
+    return true;
+  }
+  static constexpr int region_elems() {            // per-wave LDS region shared by all wave-local exchanges
+    int m = 1 << WSH;
+    for (int e = 0; e + 1 < PHASES; ++e)
+      if (ex_wave_local(e) && lay_span(e, 1 << WSH) > m) m = lay_span(e, 1 << WSH);
+    return m;
+  }
   static constexpr int lds_elems() {
-    int m = N;
-    for (int e = 0; e + 1 < PHASES; ++e) m = ex_elems(e) > m ? ex_elems(e) : m;
+    int m = region_elems() << WB;
+    for (int e = 0; e + 1 < PHASES; ++e)
+      if (!ex_wave_local(e) && lay_span(e, N) > m) m = lay_span(e, N);
     return m;
   }
   TN_HD static u32 jidx(int p, u32 tau, u32 r) {
     const int ps = pos(p);
     return ((tau >> ps) << (ps + LPT)) | (r << ps) | (tau & ((1u << ps) - 1u));
   }
-  TN_HD static u32 ex_addr(int e, u32 j) { return j + (u32)ex_pad(e) * (j >> ex_sh(e)); }
+  TN_HD static u32 ex_addr(int e, u32 j) {
+    if (WB > 0 && ex_wave_local(e)) {
+      const u32 x = j & ((1u << WSH) - 1u);
+      return (j >> WSH) * (u32)region_elems() + x + (u32)ex_pad(e) * (x >> ex_sh(e));
+    }
+    return j + (u32)ex_pad(e) * (j >> ex_sh(e));
+  }
+  // the part of the twiddle index that comes from the thread id; a compile-time 0 where every
+  // thread of the workgroup shares the twiddles (phase 0), so those loads become scalar loads
+  TN_HD static u32 thi(int p, u32 tau) { return pos(p) >= LOGN - LPT ? 0u : (tau >> pos(p)); }
 };
 
 // ---------------------------------------------------------------------------
@@ -75,8 +105,22 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
 // small and LIMIT*q <= 2^W; checked at plan creation (plan.cpp).
 // Canonical: every value in [0,q) after every operation; any odd q < 2^62 / 2^31.
 template <typename E> struct LazyTraits;
-template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 3; };   // mul_tw_lazy < 3q
+template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4; };   // mul_tw_lazy < 4q
 template <> struct LazyTraits<u32> { static constexpr int LIMIT = 64, TMUL = 2; };   // mul_tw_lazy < 2q
+
+// Lazy Cooley-Tukey butterfly: u' = u + t, v' = u - t + TMUL*q with t = v*w mod q + {0..TMUL-1}q.
+// 64-bit lanes: the add of u rides on the mad chain for free, and v' = 2u + 4q - u'
+// (computed mod 2^64; the true value u + 4q - t fits by the lazy bound).
+TN_HD void ct_lazy(u64& u, u64& v, Tw64 w, u64 q) {
+  const u64 x = mul_tw_acc(u, v, w, q);
+  v = ((u << 1) + 4 * q) - x;
+  u = x;
+}
+TN_HD void ct_lazy(u32& u, u32& v, Tw32 w, u32 q) {
+  const u32 t = mul_tw_lazy(v, w, q);                           // < 2q
+  v = u + (2 * q - t);
+  u = u + t;
+}
 
 template <typename E, bool LAZY> struct Policy {
   typedef typename TwOf<E>::type Tw;
@@ -95,10 +139,7 @@ template <typename E, bool LAZY> struct Policy {
   // Cooley-Tukey: (u, v) -> (u + w v, u - w v)
   TN_HD static void ct(E& u, E& v, Tw w, const Arith<E>& ar) {
     if (LAZY) {
-      E t = mul_tw_lazy(v, w, ar.q);                           // < TMUL q
-      E cq = (E)TMUL * ar.q;
-      v = u + (cq - t);
-      u = u + t;
+      ct_lazy(u, v, w, ar.q);
     } else {
       E t = mul_tw(v, w, ar.q);
       E s = u + t;
@@ -156,7 +197,7 @@ template <typename P, int LOGN> struct Sched {
 template <typename E, typename Cfg, typename Pol, int PH>
 TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar) {
   typedef Sched<Pol, Cfg::LOGN> S;
-  const u32 thi = tau >> Cfg::pos(PH);
+  const u32 thi = Cfg::thi(PH, tau);
   static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
@@ -173,11 +214,36 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __re
   });
 }
 
+// The same forward phase on TWO polynomials at once (a and b of one product): every twiddle
+// is loaded once and used for both butterflies, and the two chains interleave.
+template <typename E, typename Cfg, typename Pol, int PH>
+TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
+                          const Arith<E>& ar) {
+  typedef Sched<Pol, Cfg::LOGN> S;
+  const u32 thi = Cfg::thi(PH, tau);
+  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    if (S::fwd_fold(s)) {
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) { x[r] = fold(x[r], ar.k, ar.fold_c); y[r] = fold(y[r], ar.k, ar.fold_c); }
+    }
+    const u32 base = (1u << s) + (thi << (Cfg::LPT - bpos - 1));
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) {
+      if (r & (1 << bpos)) continue;
+      const typename TwOf<E>::type w = tw[base + (r >> (bpos + 1))];
+      Pol::ct(x[r], x[r | (1 << bpos)], w, ar);
+      Pol::ct(y[r], y[r | (1 << bpos)], w, ar);
+    }
+  });
+}
+
 // One inverse phase (stages of phase PH in reverse order).
 template <typename E, typename Cfg, typename Pol, int PH>
 TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar) {
   typedef Sched<Pol, Cfg::LOGN> S;
-  const u32 thi = tau >> Cfg::pos(PH);
+  const u32 thi = Cfg::thi(PH, tau);
   static_for<0, Cfg::stage_end(PH) - Cfg::stage_begin(PH)>([&](auto i_) {
     constexpr int s = Cfg::stage_end(PH) - 1 - decltype(i_)::value;   // forward stage number being undone
     constexpr int g = Cfg::LOGN - 1 - s;                               // execution order of the inverse

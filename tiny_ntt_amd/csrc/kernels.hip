@@ -15,22 +15,63 @@
 #include <hip/hip_runtime.h>
 #include "plan.h"
 
+#ifndef TN_FUSED_PAIR
+#define TN_FUSED_PAIR 0          // 1: transform a and b phase by phase together (shared twiddle loads, more live registers)
+#endif
+#ifndef TN_FUSED_LPT12
+#define TN_FUSED_LPT12 3         // log2(coefficients per thread) for n = 4096
+#endif
+#ifndef TN_FUSED_MIN_WAVES
+#define TN_FUSED_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (4 -> <= 128 VGPRs)
+#endif
+
 namespace tn {
 
 // ============================================================================
 // Fused kernel
 // ============================================================================
+// One LDS transpose between register layouts.  Data that crosses waves needs workgroup
+// barriers on all three sides (the buffer is shared with the wave-private transposes before
+// and after); a wave-local transpose only needs the compiler not to reorder it (the LDS
+// operations of one wave execute in issue order and touch that wave's private region).
+template <typename E, typename Cfg, int EX, int FROM, int TO>
+__device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
+  if constexpr (Cfg::ex_wave_local(EX)) {
+    __builtin_amdgcn_wave_barrier();
+    ex_store<E, Cfg, EX, FROM>(x, tau, lds);
+    __builtin_amdgcn_wave_barrier();
+    ex_load<E, Cfg, EX, TO>(x, tau, lds);
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+    ex_store<E, Cfg, EX, FROM>(x, tau, lds);
+    __syncthreads();
+    ex_load<E, Cfg, EX, TO>(x, tau, lds);
+    __syncthreads();
+  }
+}
+
 template <typename E, typename Cfg, typename Pol>
 __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
                                             const Arith<E>& ar, E* lds) {
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    if constexpr (p + 1 < Cfg::PHASES) exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
+  });
+}
+
+// Forward transform of both operands of one product, phase by phase, sharing twiddles.
+// One LDS image is reused for both transposes (a, then b): 4 barriers per exchange point.
+template <typename E, typename Cfg, typename Pol>
+__device__ __forceinline__ void forward_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau,
+                                             const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar, E* lds) {
+  static_for<0, Cfg::PHASES>([&](auto p_) {
+    constexpr int p = decltype(p_)::value;
+    fwd_phase_pair<E, Cfg, Pol, p>(x, y, tau, tw, ar);
     if constexpr (p + 1 < Cfg::PHASES) {
-      ex_store<E, Cfg, p, p>(x, tau, lds);
-      __syncthreads();
-      ex_load<E, Cfg, p, p + 1>(x, tau, lds);
-      __syncthreads();
+      exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
+      exchange<E, Cfg, p, p, p + 1>(y, tau, lds);
     }
   });
 }
@@ -41,17 +82,12 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const typen
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
-    if constexpr (p > 0) {
-      ex_store<E, Cfg, p - 1, p>(x, tau, lds);
-      __syncthreads();
-      ex_load<E, Cfg, p - 1, p - 1>(x, tau, lds);
-      __syncthreads();
-    }
+    if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
   });
 }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
-__global__ void __launch_bounds__((1 << (LOGN - LPT)))
+__global__ void __launch_bounds__((1 << (LOGN - LPT)), TN_FUSED_MIN_WAVES)
 polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ c, u32 batch) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
@@ -62,12 +98,24 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
   for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
     const size_t off = (size_t)row << LOGN;
     E xa[Cfg::R], xb[Cfg::R];
+    // both operands' HBM loads are issued up front; b's are consumed after a's forward transform
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(a[off + Cfg::jidx(0, tau, r)], ar);
+    for (int r = 0; r < Cfg::R; ++r) {
+      xa[r] = a[off + Cfg::jidx(0, tau, r)];
+      xb[r] = b[off + Cfg::jidx(0, tau, r)];
+    }
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(xa[r], ar);
+#if !TN_FUSED_PAIR
     forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, ar, lds);
+#endif
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(b[off + Cfg::jidx(0, tau, r)], ar);
+    for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(xb[r], ar);
+#if TN_FUSED_PAIR
+    forward_pair<E, Cfg, Pol>(xa, xb, tau, pv.psi_brv, ar, lds);
+#else
     forward_all<E, Cfg, Pol>(xb, tau, pv.psi_brv, ar, lds);
+#endif
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     inverse_all<E, Cfg, Pol>(xa, tau, pv.psi_inv_brv, ar, lds);
 #pragma unroll
@@ -80,7 +128,7 @@ static int fused_lpt(u32 logn) {
   switch (logn) {
     case 8: return 2;
     case 10: return 4;
-    case 12: return 4;
+    case 12: return TN_FUSED_LPT12;
     default: return 0;
   }
 }
@@ -106,7 +154,7 @@ static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b,
   switch (p->logn) {
     case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s);
     case 10: return launch_fused_t<E, 10, 4, LAZY>(p, a, b, c, batch, s);
-    case 12: return launch_fused_t<E, 12, 4, LAZY>(p, a, b, c, batch, s);
+    case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -57,30 +57,58 @@ TN_HD u64 mulhi64(u64 a, u64 b) {
 #endif
 }
 
-// >= floor(a*wp / 2^64) - 1, never above it: drops the a0*wp0 partial product
-// (worth < 1) but carries the middle sum exactly.  3 mads + carry fix-up.
-TN_HD u64 mulhi64_lo1(u64 a, u64 wp) {
-  u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
-  u64 m = (u64)a0 * p1;
-  u64 t = (u64)a1 * p0;
-  m += t;
-  u64 c = (m < t) ? ((u64)1 << 32) : 0;
-  return (u64)a1 * p1 + (m >> 32) + c;
+// ---- 64-bit lanes -----------------------------------------------------------
+// Makes a value opaque to LLVM at this point (no instruction is emitted).  Used so that a
+// chain of 32x32+64 multiply-adds whose consumer needs only the low dword is NOT narrowed
+// into v_mul_lo_u32 + v_add3_u32 (6 issue slots) but stays 4 v_mad_u64_u32.
+TN_HD u64 opaque64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+  return x;
 }
 
-// ---- 64-bit lanes -----------------------------------------------------------
-// a: ANY u64;  result == a*w (mod q), in [0, 3q).  Needs 3q < 2^64.
-TN_HD u64 mul_tw_lazy(u64 a, Tw64 t, u64 q) {
-  u64 qh = mulhi64_lo1(a, t.wp);      // in {Q-2, Q-1, Q}, Q = floor(a*w/q)
-  return a * t.w - qh * q;            // wraps mod 2^64; true value < 3q
+TN_HD u32 mulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
+
+// In {T-2, T-1, T} for T = floor(a*wp / 2^64): the high partial product plus the high
+// halves of the two middle ones; what is dropped (their low halves and a0*wp0) is < 3*2^64... / 2^64 < 3,
+// and floor() of the kept part can fall at most 2 below.  v_mul_hi_u32 x2 + v_mad_u64_u32 + 64-bit add.
+TN_HD u64 mulhi64_lo2(u64 a, u64 wp) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+  return ((u64)a1 * p1 + mulhi32(a0, p1)) + mulhi32(a1, p0);
 }
+
+// u + a*w - qh*q (mod 2^64) with qh ~ floor(a*w/q):  the low dword pair accumulates
+// a0*w0 + qh0*nq0 on top of u (nq = 2^64 - q; two mads with a 64-bit addend, so the add
+// of u is free); the cross terms a0*w1 + a1*w0 + qh0*nq1 + qh1*nq0 only matter mod 2^32
+// and are summed in a second mad chain whose low dword is added to the high dword.
+// a: ANY u64.  Result == u + a*w (mod q); as an integer it is u + (a*w mod q) + j*q with
+// j in {0,1,2,3} (Shoup's quotient is at most 1 low, mulhi64_lo2 at most 2 more),
+// provided that fits in 64 bits.
+TN_HD u64 mul_tw_acc(u64 u, u64 a, Tw64 t, u64 q) {
+  const u64 qh = mulhi64_lo2(a, t.wp);
+  const u64 nq = (u64)0 - q;
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), w0 = (u32)t.w, w1 = (u32)(t.w >> 32);
+  const u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  u64 lo = (u64)a0 * w0 + u;
+  lo = (u64)h0 * n0 + lo;
+  u64 hi = (u64)a0 * w1;
+  hi = (u64)a1 * w0 + hi;
+  hi = (u64)h0 * n1 + hi;
+  hi = (u64)h1 * n0 + hi;
+  hi = opaque64(hi);
+  return lo + (hi << 32);
+}
+
+// a: ANY u64;  result == a*w (mod q), in [0, 4q).  Needs 4q <= 2^64.
+TN_HD u64 mul_tw_lazy(u64 a, Tw64 t, u64 q) { return mul_tw_acc(0, a, t, q); }
 
 TN_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
 
 // canonical [0,q)
 TN_HD u64 mul_tw(u64 a, Tw64 t, u64 q) {
   u64 r = mul_tw_lazy(a, t, q);
-  r = csub(r, q);
+  r = csub(r, 2 * q);
   return csub(r, q);
 }
 

@@ -180,11 +180,22 @@ class Plan:
             raise ValueError(f"Expected {self.n} coefficients, got {cols}")
         return rows
 
-    @staticmethod
-    def _stream_ptr(stream):
-        if stream is None:
+    def _stream_ptr(self, stream):
+        """HIP stream handle for the *_dev entry points.
+
+        None  -> torch's current stream on the plan's device, so results obey normal torch stream
+                 semantics (torch's default stream has handle 0 = hipStreamLegacy, passed as
+                 TN_STREAM_LEGACY because NULL means "the plan's own stream" in the C ABI);
+        "plan" -> the plan's own non-blocking stream (call synchronize() before reading results);
+        a torch.cuda.Stream or raw integer handle -> that stream.
+        """
+        if isinstance(stream, str) and stream == "plan":
             return None
-        return ctypes.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device)
+        h = int(getattr(stream, "cuda_stream", stream))
+        return ctypes.c_void_p(h if h else 1)
 
     # ---- the operator ----------------------------------------------------------
     def poly_mult(self, a, b, variant="auto", out=None, stream=None):
@@ -266,13 +277,13 @@ class Plan:
         out = torch.empty((rows,), dtype=torch.int64, device=t.device)
         _check(self._lib, self._lib.tn_checksum_rows_dev(self._h, t.data_ptr(), out.data_ptr(), rows, self._stream_ptr(stream)))
         self.synchronize()
-        if stream is not None:
-            torch.cuda.synchronize(t.device)
-        return out.cpu().numpy().view(np.uint64)
+        return out.cpu().numpy().view(np.uint64)      # .cpu() waits on the current stream
 
     def time_poly_mult(self, a, b, c, iters: int, variant="auto") -> float:
         """Mean ms per launch over `iters` launches, HIP events on the plan's stream."""
+        import torch
         rows = self._dev_rows(a, "a")
+        torch.cuda.synchronize(self.device)            # inputs may have been produced on torch's stream
         ms = ctypes.c_float()
         _check(self._lib, self._lib.tn_time_poly_mult_dev(self._h, a.data_ptr(), b.data_ptr(), c.data_ptr(), rows, _variant(variant), iters, ctypes.byref(ms)))
         return float(ms.value)
@@ -286,7 +297,7 @@ class Plan:
     def to_host(self, t) -> np.ndarray:
         """Device tensor -> numpy array of the plan's unsigned dtype."""
         self.synchronize()
-        return t.cpu().numpy().view(self.dtype)
+        return t.cpu().numpy().view(self.dtype)       # .cpu() waits on the current stream
 
     def to_device(self, arr):
         import torch
