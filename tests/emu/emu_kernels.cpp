@@ -25,10 +25,19 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
   struct Regs { E x[Cfg::R]; };
   std::vector<Regs> xa(Cfg::THREADS), xb(Cfg::THREADS);
 
+  // host copies of what the kernel stages in LDS / prefetches into registers
+  std::vector<Tw> lds_fwd(psi_brv.begin() + Cfg::lds_tw_lo(), psi_brv.begin() + Cfg::lds_tw_hi());
+  std::vector<Tw> lds_inv(psi_inv_brv.begin() + Cfg::lds_tw_lo(), psi_inv_brv.begin() + Cfg::lds_tw_hi());
+  struct Pre { Tw t[Cfg::NPRE]; };
+  std::vector<Pre> pre(Cfg::THREADS);
+
   auto forward = [&](std::vector<Regs>& x) {
     static_for<0, Cfg::PHASES>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
-      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) fwd_phase<E, Cfg, Pol, p>(x[tau].x, tau, psi_brv.data(), ar);
+      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) {
+        const TwRefs<E> tw = {psi_brv.data(), lds_fwd.data(), pre[tau].t};
+        fwd_phase<E, Cfg, Pol, p>(x[tau].x, tau, tw, ar);
+      }
       if constexpr (p + 1 < Cfg::PHASES) {
         for (auto& v : lds) v = (E)0xDEADBEEFu;
         for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p, p>(x[tau].x, tau, lds.data());
@@ -37,9 +46,13 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
     });
   };
   auto inverse = [&](std::vector<Regs>& x) {
+    for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) tw_prefetch<E, Cfg>(pre[tau].t, tau, psi_inv_brv.data());
     static_for<0, Cfg::PHASES>([&](auto i_) {
       constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
-      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) inv_phase<E, Cfg, Pol, p>(x[tau].x, tau, psi_inv_brv.data(), ar);
+      for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) {
+        const TwRefs<E> tw = {psi_inv_brv.data(), lds_inv.data(), pre[tau].t};
+        inv_phase<E, Cfg, Pol, p>(x[tau].x, tau, tw, ar);
+      }
       if constexpr (p > 0) {
         for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p - 1, p>(x[tau].x, tau, lds.data());
         for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_load<E, Cfg, p - 1, p - 1>(x[tau].x, tau, lds.data());
@@ -54,22 +67,8 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
         xa[tau].x[r] = Pol::load((E)a[off + Cfg::jidx(0, tau, r)], ar);
         xb[tau].x[r] = Pol::load((E)b[off + Cfg::jidx(0, tau, r)], ar);
       }
-    if (row & 1) {            // odd rows: the kernel's pair schedule; even rows: one operand at a time
-      static_for<0, Cfg::PHASES>([&](auto p_) {
-        constexpr int p = decltype(p_)::value;
-        for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
-          fwd_phase_pair<E, Cfg, Pol, p>(xa[tau].x, xb[tau].x, tau, psi_brv.data(), ar);
-        if constexpr (p + 1 < Cfg::PHASES) {
-          for (auto* x : {&xa, &xb}) {
-            for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_store<E, Cfg, p, p>((*x)[tau].x, tau, lds.data());
-            for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) ex_load<E, Cfg, p, p + 1>((*x)[tau].x, tau, lds.data());
-          }
-        }
-      });
-    } else {
-      forward(xa);
-      forward(xb);
-    }
+    forward(xa);
+    forward(xb);
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) pointwise<E, Cfg, Pol>(xa[tau].x, xb[tau].x, ar);
     inverse(xa);
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
@@ -134,6 +133,23 @@ int cg_emu(const HostTables& t, int mode, const u64* a, const u64* b, u64* out, 
   return 0;
 }
 
+// Layout probes for the LDS bank-conflict simulator (tests/test_lds_banks.py).
+// what: 0 THREADS, 1 R, 2 PHASES, 3 lds_elems, 4 ex_wave_local(arg0), 5 jidx(arg0=phase, arg1=tau, arg2=r),
+//       6 ex_addr(arg0=exchange, arg1=j), 7 pos(arg0)
+template <typename E, int LOGN, int LPT> static long cfg_probe(int what, unsigned a0, unsigned a1, unsigned a2) {
+  typedef FusedCfg<E, LOGN, LPT> C;
+  switch (what) {
+    case 0: return C::THREADS;
+    case 1: return C::R;
+    case 2: return C::PHASES;
+    case 3: return C::lds_elems();
+    case 4: return C::ex_wave_local((int)a0);
+    case 5: return C::jidx((int)a0, a1, a2);
+    case 6: return C::ex_addr((int)a0, a1);
+    case 7: return C::pos((int)a0);
+  }
+  return -1;
+}
 bool params_ok(u32 n, u64 q, u64 psi) {
   if (n < 4 || (n & (n - 1)) || q < 3 || !(q & 1) || q >= ((u64)1 << 62)) return false;
   return h_powmod(psi % q, n, q) == q - 1;
@@ -162,6 +178,20 @@ int emu_cg(uint32_t n, uint64_t q, uint64_t psi, int mode, const uint64_t* a, co
   if (!params_ok(n, q, psi)) return 2;
   const HostTables t = h_build_tables(n, q, psi, true);
   return t.elem_bytes == 8 ? cg_emu<u64>(t, mode, a, b, out, trace) : cg_emu<u32>(t, mode, a, b, out, trace);
+}
+
+// see cfg_probe() above for `what`
+long emu_cfg_probe(int logn, int elem_bytes, int what, unsigned a0, unsigned a1, unsigned a2) {
+  if (elem_bytes == 8) {
+    if (logn == 8) return cfg_probe<u64, 8, 2>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u64, 10, 4>(what, a0, a1, a2);
+    if (logn == 12) return cfg_probe<u64, 12, 3>(what, a0, a1, a2);
+  } else {
+    if (logn == 8) return cfg_probe<u32, 8, 2>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u32, 10, 4>(what, a0, a1, a2);
+    if (logn == 12) return cfg_probe<u32, 12, 3>(what, a0, a1, a2);
+  }
+  return -1;
 }
 
 // Direct probes of the arithmetic primitives (for property tests).

@@ -93,6 +93,10 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
   p->k = t.k; p->mu = t.mu; p->lazy = t.lazy; p->fold_c = t.fold_c;
   p->has_fused = fused_supported(logn, elem_bytes);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount;
+  }
   set_tw(1, q, elem_bytes, &p->one_w, &p->one_wp);
   set_tw(t.n_inv, q, elem_bytes, &p->ninv_w, &p->ninv_wp);
   set_tw(t.ninv_w1, q, elem_bytes, &p->ninv_w1_w, &p->ninv_w1_wp);

@@ -24,6 +24,17 @@
 #include <type_traits>
 #include "modarith.h"
 
+// Timing-ablation switches (developer experiments only; results are wrong when set).
+#ifndef TN_BFLY_FENCE
+#define TN_BFLY_FENCE 0          // >0: scheduling fence after every TN_BFLY_FENCE twiddle groups of a stage
+#endif
+#ifndef TN_PREFETCH_LAST
+#define TN_PREFETCH_LAST 0       // 1: last-phase (thread-private) twiddles are fetched one stage early into registers (costs 28 VGPRs: spills at 128)
+#endif
+#ifndef TN_ABL_UNIFORM_TW
+#define TN_ABL_UNIFORM_TW 0      // 1: every thread uses the phase-0 (wave-uniform) twiddle indices -> no vector twiddle loads
+#endif
+
 namespace tn {
 
 template <int B, int E_, typename F> struct StaticFor {
@@ -74,7 +85,17 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
       if (ex_wave_local(e) && lay_span(e, 1 << WSH) > m) m = lay_span(e, 1 << WSH);
     return m;
   }
+  // n = 4096, 64-bit, 8 coefficients per thread: XOR-swizzled images instead of padded ones, so the
+  // transpose buffer is exactly one polynomial (32 KiB) and two workgroups per CU fit beside the
+  // parked operand and the LDS twiddle tables.  With j = (w:3 | g:3 | m:3 | e:3):
+  //   exchange 0 (phase 0 <-> 1): both sides touch 64 contiguous coefficients per wave-instruction: identity;
+  //   exchange 1 (1 <-> 2): m[1:0] ^= g[1:0];
+  //   exchange 2 (2 <-> 3): m[1:0] ^= g[1:0], e[2] ^= m[2] ^ g[1], e[1] ^= m[1]
+  // (bank-conflict free for the ds_{read,write}_b64 / _b128 lane groups of gfx950; checked by
+  // tests/test_lds_banks.py with a bank simulator).
+  static constexpr bool SWZ = (sizeof(E) == 8 && LOGN == 12 && LPT == 3);
   static constexpr int lds_elems() {
+    if (SWZ) return N;
     int m = region_elems() << WB;
     for (int e = 0; e + 1 < PHASES; ++e)
       if (!ex_wave_local(e) && lay_span(e, N) > m) m = lay_span(e, N);
@@ -85,15 +106,55 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
     return ((tau >> ps) << (ps + LPT)) | (r << ps) | (tau & ((1u << ps) - 1u));
   }
   TN_HD static u32 ex_addr(int e, u32 j) {
+    if (SWZ) {
+      if (e == 0) return j;
+      const u32 g = (j >> 6) & 7u, m = (j >> 3) & 7u;
+      u32 a = j ^ ((g & 3u) << 3);
+      if (e == 2) a ^= ((((m >> 2) ^ (g >> 1)) & 1u) << 2) | (((m >> 1) & 1u) << 1);
+      return a;
+    }
     if (WB > 0 && ex_wave_local(e)) {
       const u32 x = j & ((1u << WSH) - 1u);
       return (j >> WSH) * (u32)region_elems() + x + (u32)ex_pad(e) * (x >> ex_sh(e));
     }
     return j + (u32)ex_pad(e) * (j >> ex_sh(e));
   }
+  // Where the twiddles of phase p come from:
+  //   TW_UNIFORM  every thread of the workgroup uses the same ones        -> scalar loads
+  //   TW_WAVE     the same within a wave (index depends on the wave id)     -> scalar loads
+  //   TW_LDS      lane-dependent, table small: staged once per workgroup in LDS
+  //   TW_REGS     last phase: one private set per thread, fetched from the L2-resident table
+  //               one phase ahead into registers (pre[])
+  enum { TW_UNIFORM = 0, TW_WAVE = 1, TW_LDS = 2, TW_REGS = 3 };
+  static constexpr int tw_src(int p) {
+    return pos(p) >= LOGN - LPT ? TW_UNIFORM : (pos(p) >= 6 ? TW_WAVE : (pos(p) > 0 ? TW_LDS : (TN_PREFETCH_LAST ? TW_REGS : TW_WAVE)));
+  }
+  static constexpr int lds_tw_lo() {                 // first table index kept in LDS
+    for (int p = 0; p < PHASES; ++p) if (tw_src(p) == TW_LDS) return 1 << stage_begin(p);
+    return 0;
+  }
+  static constexpr int lds_tw_hi() {                 // one past the last
+    int h = 0;
+    for (int p = 0; p < PHASES; ++p) if (tw_src(p) == TW_LDS) h = 1 << stage_end(p);
+    return h;
+  }
+  static constexpr int lds_tw_count() { return lds_tw_hi() - lds_tw_lo(); }
+  // private twiddles of the last phase: stage s contributes R >> (bpos+1) of them
+  static constexpr int pre_count(int s) { return R >> ((LOGN - 1 - s) - pos(PHASES - 1) + 1); }
+  static constexpr int pre_off(int s) {
+    int o = 0;
+    for (int i = stage_begin(PHASES - 1); i < s; ++i) o += pre_count(i);
+    return o;
+  }
+  static constexpr int NPRE = (tw_src(PHASES - 1) == TW_REGS) ? pre_off(LOGN) : 1;
   // the part of the twiddle index that comes from the thread id; a compile-time 0 where every
   // thread of the workgroup shares the twiddles (phase 0), so those loads become scalar loads
-  TN_HD static u32 thi(int p, u32 tau) { return pos(p) >= LOGN - LPT ? 0u : (tau >> pos(p)); }
+  // ... and wave-uniform (made a scalar) where it only depends on the wave index (pos(p) >= 6).
+  TN_HD static u32 thi(int p, u32 tau) {
+    if (pos(p) >= LOGN - LPT) return 0u;
+    if (pos(p) >= 6) return wave_uniform(tau >> pos(p));
+    return tau >> pos(p);
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -184,7 +245,7 @@ template <typename P, int LOGN> struct Sched {
   }
   // inverse stage index g = 0 .. LOGN-1 in execution order (g = 0 is distance 1)
   static constexpr int inv_in(int g) {
-    int b = 1;                                   // pointwise output is canonical
+    int b = P::lazy ? 4 : 1;                     // pointwise output: lazy Barrett < 4q, else canonical
     for (int i = 0; i < g; ++i) { if (2 * b > P::LIMIT) b = 2; b = (2 * b > P::TMUL) ? 2 * b : P::TMUL; }
     return b;
   }
@@ -192,24 +253,66 @@ template <typename P, int LOGN> struct Sched {
   static constexpr int inv_bnd(int g) { return inv_fold(g) ? 2 : inv_in(g); }
 };
 
+// The three places a phase can take its twiddles from (see FusedCfg::tw_src).
+template <typename E> struct TwRefs {
+  typedef typename TwOf<E>::type Tw;
+  const Tw* __restrict__ glob;     // full table psi^brv(i) (or inverse) in global memory / L2
+  const Tw* lds;                   // entries [lds_tw_lo, lds_tw_hi) of it, staged in LDS
+  Tw* pre;                         // the calling thread's last-phase twiddles, in registers
+};
+
+template <typename E, typename Cfg, int PH, int S_>
+TN_HD typename TwOf<E>::type tw_get(const TwRefs<E>& t, u32 thi, int g) {
+  constexpr int bpos = (Cfg::LOGN - 1 - S_) - Cfg::pos(PH);
+  if (Cfg::tw_src(PH) == Cfg::TW_REGS) return t.pre[Cfg::pre_off(S_) + g];
+  const u32 idx = (1u << S_) + (TN_ABL_UNIFORM_TW ? 0u : (thi << (Cfg::LPT - bpos - 1))) + (u32)g;
+  if (Cfg::tw_src(PH) == Cfg::TW_LDS) return t.lds[idx - Cfg::lds_tw_lo()];
+  return t.glob[idx];
+}
+
+// Fetch the calling thread's last-phase twiddles into registers (issued ahead of their use).
+template <typename E, typename Cfg>
+TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+  constexpr int PH = Cfg::PHASES - 1;
+  if (Cfg::tw_src(PH) != Cfg::TW_REGS) return;
+  const u32 thi = Cfg::thi(PH, tau);
+  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+#pragma unroll
+    for (int g = 0; g < Cfg::pre_count(s); ++g)
+      pre[Cfg::pre_off(s) + g] = glob[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g];
+  });
+}
+template <typename E, typename Cfg>
+TN_HD void tw_prefetch(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+  tw_prefetch_raw<E, Cfg>(pre, tau, glob);
+}
+
 // ---------------------------------------------------------------------------
 // One forward phase on a thread's registers.
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar) {
+TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
   typedef Sched<Pol, Cfg::LOGN> S;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    // the next (last) phase's thread-private twiddles are requested from L2 one stage early
+    if (Cfg::PHASES >= 2 && PH == Cfg::PHASES - 2 && s == Cfg::stage_end(PH) - 1 && Cfg::tw_src(Cfg::PHASES - 1) == Cfg::TW_REGS) {
+      sched_fence();
+      tw_prefetch_raw<E, Cfg>(tw.pre, tau, tw.glob);
+      sched_fence();
+    }
     if (S::fwd_fold(s)) {
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) x[r] = fold(x[r], ar.k, ar.fold_c);
     }
-    const u32 base = (1u << s) + (thi << (Cfg::LPT - bpos - 1));
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) {
       if (r & (1 << bpos)) continue;
-      Pol::ct(x[r], x[r | (1 << bpos)], tw[base + (r >> (bpos + 1))], ar);
+      Pol::ct(x[r], x[r | (1 << bpos)], tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1)), ar);
+      if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
     }
   });
 }
@@ -217,8 +320,7 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __re
 // The same forward phase on TWO polynomials at once (a and b of one product): every twiddle
 // is loaded once and used for both butterflies, and the two chains interleave.
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
-                          const Arith<E>& ar) {
+TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
   typedef Sched<Pol, Cfg::LOGN> S;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
@@ -228,11 +330,10 @@ TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const typenam
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) { x[r] = fold(x[r], ar.k, ar.fold_c); y[r] = fold(y[r], ar.k, ar.fold_c); }
     }
-    const u32 base = (1u << s) + (thi << (Cfg::LPT - bpos - 1));
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) {
       if (r & (1 << bpos)) continue;
-      const typename TwOf<E>::type w = tw[base + (r >> (bpos + 1))];
+      const typename TwOf<E>::type w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
       Pol::ct(x[r], x[r | (1 << bpos)], w, ar);
       Pol::ct(y[r], y[r | (1 << bpos)], w, ar);
     }
@@ -241,7 +342,7 @@ TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const typenam
 
 // One inverse phase (stages of phase PH in reverse order).
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar) {
+TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
   typedef Sched<Pol, Cfg::LOGN> S;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<0, Cfg::stage_end(PH) - Cfg::stage_begin(PH)>([&](auto i_) {
@@ -253,35 +354,59 @@ TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __re
       for (int r = 0; r < Cfg::R; ++r) x[r] = fold(x[r], ar.k, ar.fold_c);
     }
     constexpr int BND = S::inv_bnd(g);
-    const u32 base = (1u << s) + (thi << (Cfg::LPT - bpos - 1));
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) {
       if (r & (1 << bpos)) continue;
       if (s == 0) Pol::template gs_last<BND>(x[r], x[r | (1 << bpos)], ar);
-      else Pol::template gs<BND>(x[r], x[r | (1 << bpos)], tw[base + (r >> (bpos + 1))], ar);
+      else Pol::template gs<BND>(x[r], x[r | (1 << bpos)], tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1)), ar);
+      if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
     }
   });
 }
 
 // LDS transposes.  e = exchange index (between phase e and e+1); `from` = phase
 // whose register layout is being written, `to` = phase whose layout is read.
+struct alignas(16) Pair64 { u64 lo, hi; };
 template <typename E, typename Cfg, int EX, int PH>
 TN_HD void ex_store(const E (&x)[Cfg::R], u32 tau, E* lds) {
+  if constexpr (Cfg::SWZ && Cfg::pos(PH) == 0) {       // thread owns 8 consecutive coefficients: 16-byte stores
 #pragma unroll
-  for (int r = 0; r < Cfg::R; ++r) lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))] = x[r];
+    for (int r = 0; r < Cfg::R; r += 2) {
+      Pair64 v; v.lo = x[r]; v.hi = x[r + 1];
+      *reinterpret_cast<Pair64*>(lds + Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))) = v;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))] = x[r];
+  }
 }
 template <typename E, typename Cfg, int EX, int PH>
 TN_HD void ex_load(E (&x)[Cfg::R], u32 tau, const E* lds) {
+  if constexpr (Cfg::SWZ && Cfg::pos(PH) == 0) {
 #pragma unroll
-  for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))];
+    for (int r = 0; r < Cfg::R; r += 2) {
+      const Pair64 v = *reinterpret_cast<const Pair64*>(lds + Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r)));
+      x[r] = (E)v.lo; x[r + 1] = (E)v.hi;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))];
+  }
 }
 
-// Pointwise product in the last phase's register layout: canonical result.
+// Pointwise product in the last phase's register layout.  Canonical policy: canonical result.
+// Lazy policy: operands are folded below 2^k + eps and the Barrett product is left in [0, 4q)
+// (Sched::inv_in starts from that bound), which saves four conditional subtractions per product.
 template <typename E, typename Cfg, typename Pol>
 TN_HD void pointwise(E (&xa)[Cfg::R], const E (&xb)[Cfg::R], const Arith<E>& ar) {
 #pragma unroll
-  for (int r = 0; r < Cfg::R; ++r)
-    xa[r] = mulmod_barrett(Pol::canon(xa[r], ar), Pol::canon(xb[r], ar), ar.q, ar.mu, ar.k);
+  for (int r = 0; r < Cfg::R; ++r) {
+    if (Pol::lazy)
+      xa[r] = mulmod_barrett_lazy(fold(xa[r], ar.k, ar.fold_c), fold(xb[r], ar.k, ar.fold_c), ar.q, ar.mu, ar.k);
+    else
+      xa[r] = mulmod_barrett(xa[r], xb[r], ar.q, ar.mu, ar.k);
+    if (r & 1) sched_fence();          // two products in flight at a time: bounds the live temporaries
+  }
 }
 
 }  // namespace tn

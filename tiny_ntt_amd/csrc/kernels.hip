@@ -15,6 +15,15 @@
 #include <hip/hip_runtime.h>
 #include "plan.h"
 
+#ifndef TN_ABL_NO_BARRIER
+#define TN_ABL_NO_BARRIER 0      // timing ablation: cross-wave transposes without workgroup barriers (wrong results)
+#endif
+#ifndef TN_ABL_NO_GLOBAL
+#define TN_ABL_NO_GLOBAL 0       // timing ablation: operands synthesised in registers instead of loaded from HBM
+#endif
+#ifndef TN_PARK_LDS
+#define TN_PARK_LDS 1            // 1: A^ waits in LDS (not registers) while b is transformed
+#endif
 #ifndef TN_FUSED_PAIR
 #define TN_FUSED_PAIR 0          // 1: transform a and b phase by phase together (shared twiddle loads, more live registers)
 #endif
@@ -43,17 +52,29 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
     ex_load<E, Cfg, EX, TO>(x, tau, lds);
     __builtin_amdgcn_wave_barrier();
   } else {
+#if TN_ABL_NO_BARRIER
+    __builtin_amdgcn_wave_barrier();
+    ex_store<E, Cfg, EX, FROM>(x, tau, lds);
+    __builtin_amdgcn_wave_barrier();
+    ex_load<E, Cfg, EX, TO>(x, tau, lds);
+    __builtin_amdgcn_wave_barrier();
+#else
     __syncthreads();
     ex_store<E, Cfg, EX, FROM>(x, tau, lds);
     __syncthreads();
     ex_load<E, Cfg, EX, TO>(x, tau, lds);
     __syncthreads();
+#endif
   }
 }
 
+// Forward transform.  The thread-private twiddles of the last phase are requested from L2 one
+// stage early (into pre[], inside fwd_phase), so their latency hides behind that stage and the transpose.
 template <typename E, typename Cfg, typename Pol>
-__device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
-                                            const Arith<E>& ar, E* lds) {
+__device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
+                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds) {
+  typename TwOf<E>::type pre[Cfg::NPRE];
+  const TwRefs<E> tw = {glob, lds_tw, pre};
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
@@ -61,29 +82,23 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
   });
 }
 
-// Forward transform of both operands of one product, phase by phase, sharing twiddles.
-// One LDS image is reused for both transposes (a, then b): 4 barriers per exchange point.
+// Inverse transform; pre[] (last-phase twiddles, used first) was requested by the caller.
 template <typename E, typename Cfg, typename Pol>
-__device__ __forceinline__ void forward_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau,
-                                             const typename TwOf<E>::type* __restrict__ tw, const Arith<E>& ar, E* lds) {
-  static_for<0, Cfg::PHASES>([&](auto p_) {
-    constexpr int p = decltype(p_)::value;
-    fwd_phase_pair<E, Cfg, Pol, p>(x, y, tau, tw, ar);
-    if constexpr (p + 1 < Cfg::PHASES) {
-      exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
-      exchange<E, Cfg, p, p, p + 1>(y, tau, lds);
-    }
-  });
-}
-
-template <typename E, typename Cfg, typename Pol>
-__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ tw,
-                                            const Arith<E>& ar, E* lds) {
+__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds) {
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
   });
+}
+
+template <typename E, typename Cfg>
+__device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 tau, int r) {
+#if TN_ABL_NO_GLOBAL
+  return (E)(tau * 2654435761u + 7 * r + row);
+#else
+  return p[((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)];
+#endif
 }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
@@ -93,33 +108,63 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
   typedef Policy<E, LAZY> Pol;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
   E* lds = reinterpret_cast<E*>(tn_smem);
+  typedef typename TwOf<E>::type Tw;
   const u32 tau = threadIdx.x;
   const Arith<E> ar = pv.ar;
-  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
-    const size_t off = (size_t)row << LOGN;
-    E xa[Cfg::R], xb[Cfg::R];
-    // both operands' HBM loads are issued up front; b's are consumed after a's forward transform
+  // twiddles of the lane-dependent middle phases: staged once per (persistent) workgroup in LDS
+  Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0));
+  Tw* lds_inv = lds_fwd + Cfg::lds_tw_count();
+  for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) {
+    lds_fwd[i] = pv.psi_brv[Cfg::lds_tw_lo() + i];
+    lds_inv[i] = pv.psi_inv_brv[Cfg::lds_tw_lo() + i];
+  }
+  __syncthreads();
+  // Persistent workgroup: rows blockIdx.x, blockIdx.x + gridDim.x, ...  The next row's first
+  // operand is fetched from HBM into the registers that held b (dead after the pointwise
+  // product) while the inverse transform of the current row runs; b itself is requested at the
+  // top of the row and not needed until a's forward transform is done.
+  E xa[Cfg::R], xb[Cfg::R];
+  u32 row = blockIdx.x;
+  if (row < batch) {
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) {
-      xa[r] = a[off + Cfg::jidx(0, tau, r)];
-      xb[r] = b[off + Cfg::jidx(0, tau, r)];
-    }
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = ld_operand<E, Cfg>(a, row, tau, r);
+  }
+  for (; row < batch; row += gridDim.x) {
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tau, r);
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(xa[r], ar);
-#if !TN_FUSED_PAIR
-    forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, ar, lds);
+    forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, lds_fwd, ar, lds);
+#if TN_PARK_LDS
+    // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
+    E* park = lds + Cfg::lds_elems() + tau * Cfg::R;
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) park[r] = xa[r];
 #endif
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(xb[r], ar);
-#if TN_FUSED_PAIR
-    forward_pair<E, Cfg, Pol>(xa, xb, tau, pv.psi_brv, ar, lds);
-#else
-    forward_all<E, Cfg, Pol>(xb, tau, pv.psi_brv, ar, lds);
+    forward_all<E, Cfg, Pol>(xb, tau, pv.psi_brv, lds_fwd, ar, lds);
+    // the inverse starts with the thread-private phase: request its twiddles before the product
+    Tw pre[Cfg::NPRE];
+    tw_prefetch<E, Cfg>(pre, tau, pv.psi_inv_brv);
+#if TN_PARK_LDS
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = park[r];
 #endif
     pointwise<E, Cfg, Pol>(xa, xb, ar);
-    inverse_all<E, Cfg, Pol>(xa, tau, pv.psi_inv_brv, ar, lds);
+    sched_fence();                     // the prefetch below reuses b's registers: keep it behind the product
+    const u32 next = row + gridDim.x;
+    if (next < batch) {
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tau, r);
+    }
+    const TwRefs<E> twi = {pv.psi_inv_brv, lds_inv, pre};
+    inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds);
+    const size_t off = (size_t)row << LOGN;
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) c[off + Cfg::jidx(0, tau, r)] = xa[r];
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = xb[r];
   }
 }
 
@@ -138,13 +183,19 @@ bool fused_supported(u32 logn, int) { return fused_lpt(logn) != 0; }
 template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
-  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E);
+  const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0)) * sizeof(E) +
+                           (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type);
   auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  const u32 grid = (u32)(batch < (size_t)1 << 20 ? batch : (size_t)1 << 20);
+  // persistent grid: as many workgroups as can be resident (occupancy query), each looping over rows
+  int per_cu = 0;
+  hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
+  if (qe != hipSuccess || per_cu < 1) per_cu = 1;
+  const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
+  const u32 grid = (u32)(batch < resident ? batch : resident);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, make_view<E>(p), (const E*)a, (const E*)b, (E*)c, (u32)batch);
   return hipGetLastError();
 }

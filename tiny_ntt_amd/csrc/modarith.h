@@ -68,6 +68,24 @@ TN_HD u64 opaque64(u64 x) {
   return x;
 }
 
+// Scheduling fence (device only): the machine scheduler may not move instructions across it.
+// Used between groups of butterflies to bound how many are in flight (live registers).
+TN_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// Value known to be identical in all lanes of a wave: tells the compiler so (v_readfirstlane),
+// which turns loads indexed by it into scalar loads.  Host: identity.
+TN_HD u32 wave_uniform(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (u32)__builtin_amdgcn_readfirstlane((int)x);
+#else
+  return x;
+#endif
+}
+
 TN_HD u32 mulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 
 // In {T-2, T-1, T} for T = floor(a*wp / 2^64): the high partial product plus the high
@@ -123,11 +141,24 @@ TN_HD u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu, int k) {
   return csub(r, q);                                          // second subtract kept: single-subtract bound unproven
 }
 
-// One Barrett step with quotient estimate x >> k, for q = 2^k - c:  result == x (mod q),
-// < 2^k + (x >> k) * c.
+// Same recipe without the final subtractions, for operands slightly above 2^k (a, b < 2^k + 2^(k-20)):
+// then p/q - q1*mu/2^(k+1) < 2 + 2^-18, so q2 is at most 3 below floor(p/q) and the result,
+// congruent to a*b, lies in [0, 4q).
+TN_HD u64 mulmod_barrett_lazy(u64 a, u64 b, u64 q, u64 mu, int k) {
+  u64 plo = a * b, phi = mulhi64(a, b);
+  u64 q1 = (phi << (64 - (k - 1))) | (plo >> (k - 1));
+  u64 mlo = q1 * mu, mhi = mulhi64(q1, mu);
+  u64 q2 = (mhi << (64 - (k + 1))) | (mlo >> (k + 1));
+  return plo - q2 * q;
+}
+
+// One Barrett step with quotient estimate x >> k, for q = 2^k - c (k >= 32):  result == x (mod q),
+// < 2^k + (x >> k) * c.  Written on the high dword so it is 2 two-cycle ops + one v_mad_u64_u32.
 TN_HD u64 fold(u64 x, int k, u32 c) {
-  u64 lowmask = (((u64)1) << k) - 1;
-  return (x & lowmask) + (u64)(u32)(x >> k) * c;              // one v_mad_u64_u32 on device
+  const u32 hi = (u32)(x >> 32);
+  const u32 top = hi >> (k - 32);
+  const u32 keep = hi & ((1u << (k - 32)) - 1u);
+  return (((u64)keep << 32) | (u32)x) + (u64)top * c;
 }
 
 // ---- 32-bit lanes -----------------------------------------------------------
@@ -149,6 +180,13 @@ TN_HD u32 mulmod_barrett(u32 a, u32 b, u32 q, u64 mu, int k) {
   u32 r = (u32)p - (u32)q2 * q;
   r = csub(r, q);
   return csub(r, q);
+}
+
+TN_HD u32 mulmod_barrett_lazy(u32 a, u32 b, u32 q, u64 mu, int k) {
+  u64 p = (u64)a * b;
+  u64 q1 = p >> (k - 1);
+  u64 q2 = (q1 * mu) >> (k + 1);
+  return (u32)p - (u32)q2 * q;
 }
 
 TN_HD u32 fold(u32 x, int k, u32 c) {

@@ -9,6 +9,7 @@ struct tn_plan {
   tn::u32 n = 0, logn = 0;
   tn::u64 q = 0, psi = 0, omega = 0;
   int device = 0;
+  int num_cus = 256;
   tn::u32 flags = 0;
   int elem_bytes = 8;
   bool has_fused = false, lazy = false;

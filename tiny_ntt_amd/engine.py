@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtinyntt.so")
+LIB_PATH = os.environ.get("TINYNTT_LIB") or os.path.join(_HERE, "lib", "libtinyntt.so")   # env override: developer A/B builds
 
 # tn_status (include/tinyntt.h)
 TN_OK, TN_EBADLEN, TN_EBADPARAM, TN_ENODEVICE, TN_EHIP, TN_ENOMEM, TN_EINVAL, TN_EUNSUPPORTED = range(8)
