@@ -32,6 +32,7 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
   std::vector<Pre> pre(Cfg::THREADS);
 
   auto forward = [&](std::vector<Regs>& x) {
+    for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) tw_prefetch<E, Cfg>(pre[tau].t, tau, psi_brv.data());
     static_for<0, Cfg::PHASES>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
       for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) {

@@ -29,7 +29,8 @@
 #define TN_BFLY_FENCE 0          // >0: scheduling fence after every TN_BFLY_FENCE twiddle groups of a stage
 #endif
 #ifndef TN_PREFETCH_LAST
-#define TN_PREFETCH_LAST 0       // 1: last-phase (thread-private) twiddles are fetched one stage early into registers (costs 28 VGPRs: spills at 128)
+#define TN_PREFETCH_LAST 2       // last-phase (thread-private) twiddles: 0 = loaded at use; 1 = one stage early (28 VGPRs live
+                                 // through a butterfly stage: spills at 128); 2 = just before the transpose that precedes the phase
 #endif
 #ifndef TN_ABL_UNIFORM_TW
 #define TN_ABL_UNIFORM_TW 0      // 1: every thread uses the phase-0 (wave-uniform) twiddle indices -> no vector twiddle loads
@@ -299,7 +300,8 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
     constexpr int s = decltype(s_)::value;
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
     // the next (last) phase's thread-private twiddles are requested from L2 one stage early
-    if (Cfg::PHASES >= 2 && PH == Cfg::PHASES - 2 && s == Cfg::stage_end(PH) - 1 && Cfg::tw_src(Cfg::PHASES - 1) == Cfg::TW_REGS) {
+    if (TN_PREFETCH_LAST == 1 && Cfg::PHASES >= 2 && PH == Cfg::PHASES - 2 && s == Cfg::stage_end(PH) - 1 &&
+        Cfg::tw_src(Cfg::PHASES - 1) == Cfg::TW_REGS) {
       sched_fence();
       tw_prefetch_raw<E, Cfg>(tw.pre, tau, tw.glob);
       sched_fence();

@@ -21,6 +21,9 @@
 #ifndef TN_ABL_NO_GLOBAL
 #define TN_ABL_NO_GLOBAL 0       // timing ablation: operands synthesised in registers instead of loaded from HBM
 #endif
+#ifndef TN_NT_STREAM
+#define TN_NT_STREAM 1           // 1: non-temporal loads/stores for the streamed operands a, b, c
+#endif
 #ifndef TN_PARK_LDS
 #define TN_PARK_LDS 1            // 1: A^ waits in LDS (not registers) while b is transformed
 #endif
@@ -78,16 +81,26 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    if constexpr (TN_PREFETCH_LAST == 2 && p == Cfg::PHASES - 2) {
+      sched_fence();                   // request the last phase's private twiddles; they fly during the transpose
+      tw_prefetch<E, Cfg>(pre, tau, glob);
+      sched_fence();
+    }
     if constexpr (p + 1 < Cfg::PHASES) exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
   });
 }
 
-// Inverse transform; pre[] (last-phase twiddles, used first) was requested by the caller.
-template <typename E, typename Cfg, typename Pol>
-__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds) {
+// Inverse transform.  `after_first` runs once the first phase (the one whose thread-private
+// twiddles come from L2 through vector loads) has been computed: vector-memory operations
+// complete in order, so the long-latency HBM prefetch of the next row must be issued AFTER
+// those twiddle loads have been consumed, or every wave would wait for HBM at the top of the inverse.
+template <typename E, typename Cfg, typename Pol, typename F>
+__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds,
+                                            F&& after_first) {
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
     if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
   });
 }
@@ -97,7 +110,11 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 #if TN_ABL_NO_GLOBAL
   return (E)(tau * 2654435761u + 7 * r + row);
 #else
+#if TN_NT_STREAM
+  return __builtin_nontemporal_load(p + (((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)));   // streamed once: keep L2 for the twiddle tables
+#else
   return p[((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)];
+#endif
 #endif
 }
 
@@ -152,17 +169,23 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
     for (int r = 0; r < Cfg::R; ++r) xa[r] = park[r];
 #endif
     pointwise<E, Cfg, Pol>(xa, xb, ar);
-    sched_fence();                     // the prefetch below reuses b's registers: keep it behind the product
     const u32 next = row + gridDim.x;
-    if (next < batch) {
-#pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tau, r);
-    }
     const TwRefs<E> twi = {pv.psi_inv_brv, lds_inv, pre};
-    inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds);
+    inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {
+      if (next < batch) {              // next row's first operand -> the registers that held b
+#pragma unroll
+        for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tau, r);
+      }
+    });
     const size_t off = (size_t)row << LOGN;
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) c[off + Cfg::jidx(0, tau, r)] = xa[r];
+    for (int r = 0; r < Cfg::R; ++r) {
+#if TN_NT_STREAM
+      __builtin_nontemporal_store(xa[r], c + off + Cfg::jidx(0, tau, r));
+#else
+      c[off + Cfg::jidx(0, tau, r)] = xa[r];
+#endif
+    }
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xb[r];
   }

@@ -115,7 +115,8 @@ TN_HD u64 mul_tw_acc(u64 u, u64 a, Tw64 t, u64 q) {
   hi = (u64)h0 * n1 + hi;
   hi = (u64)h1 * n0 + hi;
   hi = opaque64(hi);
-  return lo + (hi << 32);
+  const u32 rh = (u32)(lo >> 32) + (u32)hi;                     // one 32-bit add on the high dword
+  return ((u64)rh << 32) | (u32)lo;
 }
 
 // a: ANY u64;  result == a*w (mod q), in [0, 4q).  Needs 4q <= 2^64.
@@ -155,10 +156,9 @@ TN_HD u64 mulmod_barrett_lazy(u64 a, u64 b, u64 q, u64 mu, int k) {
 // One Barrett step with quotient estimate x >> k, for q = 2^k - c (k >= 32):  result == x (mod q),
 // < 2^k + (x >> k) * c.  Written on the high dword so it is 2 two-cycle ops + one v_mad_u64_u32.
 TN_HD u64 fold(u64 x, int k, u32 c) {
-  const u32 hi = (u32)(x >> 32);
-  const u32 top = hi >> (k - 32);
-  const u32 keep = hi & ((1u << (k - 32)) - 1u);
-  return (((u64)keep << 32) | (u32)x) + (u64)top * c;
+  const u32 top = (u32)(x >> 32) >> (k - 32);
+  const u64 lowmask = (((u64)1) << k) - 1;
+  return (x & lowmask) + (u64)top * c;
 }
 
 // ---- 32-bit lanes -----------------------------------------------------------
