@@ -105,6 +105,8 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
   });
 }
 
+template <typename E> struct alignas(2 * sizeof(E)) PairOf { E lo, hi; };
+
 template <typename E, typename Cfg>
 __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 tau, int r) {
 #if TN_ABL_NO_GLOBAL
@@ -154,9 +156,10 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
     forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, lds_fwd, ar, lds);
 #if TN_PARK_LDS
     // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
-    E* park = lds + Cfg::lds_elems() + tau * Cfg::R;
+    // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
+    PairOf<E>* park = reinterpret_cast<PairOf<E>*>(lds + Cfg::lds_elems()) + tau;
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) park[r] = xa[r];
+    for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
 #endif
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(xb[r], ar);
@@ -166,7 +169,7 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
     tw_prefetch<E, Cfg>(pre, tau, pv.psi_inv_brv);
 #if TN_PARK_LDS
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = park[r];
+    for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
 #endif
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     const u32 next = row + gridDim.x;
