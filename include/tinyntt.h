@@ -125,6 +125,31 @@ tn_status tn_ntt_forward_trace_host(tn_plan *plan, const void *in, void *out, vo
 tn_status tn_twisted_ntt_forward_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
 
 /*
+ * Untwisted (CYCLIC) product: cg_ntt(a), cg_ntt(b), pointwise, cg_intt with omega = psi^2 —
+ * python_poly_mult (test/cocotb_tests/test_ntt_poly_mult.py:38-43), i.e. what the reference's
+ * RTL top level / RoCC accelerator computes.  CG variants only.
+ */
+tn_status tn_cyclic_poly_mult_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch,
+                                  tn_variant variant, void *stream);
+
+/* c[i] = a[i] * b[i] mod q over batch*n coefficients: pointwise_mul (benchmark_ntt_60bit.cpp:142-146; cg_ntt.py:88). */
+tn_status tn_pointwise_mul_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch, void *stream);
+
+/*
+ * O(n^2) direct negacyclic product on device — negacyclic_mul_reference (benchmark_ntt_60bit.cpp:167-180),
+ * the benchmark_simple family, negacyclic_convolution (new_reference/test_cg_ntt.py:11-21).  An
+ * independent on-device checker for the NTT path; not a throughput kernel.
+ */
+tn_status tn_schoolbook_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch, void *stream);
+
+/*
+ * Copy one of the plan's constant tables to the host as uint64_t values (the constants only,
+ * without their Barrett factors).  which: 0 psi^i [n] (= rtl/twiddle_forward*.hex), 1 psi^-i * n^-1 [n],
+ * 2 omega^j [n/2], 3 omega^-j [n/2], 4 psi^brv(i) [n], 5 psi^-brv(i) [n].
+ */
+tn_status tn_plan_export_table(tn_plan *plan, int which, void *host_out);
+
+/*
  * Synthetic inputs and digests, on device, in the reference benchmark's own
  * conventions so runs can be diffed against its printed checksums:
  * tn_fill_lcg_dev: row r gets make_poly(seed0 + r * seed_stride)

@@ -152,6 +152,26 @@ def gen(tag):
     print(tag, "cases:", len(meta["cases"]), "arrays:", len(arrays))
 
 
+def hex_digests():
+    """Digests (not copies) of the reference's on-disk twiddle tables rtl/twiddle_*.hex: the export
+    code in tiny_ntt_amd/twiddles.py must reproduce these files byte for byte."""
+    import hashlib
+    files = {"twiddle_forward_4096_60bit.hex": ("P4096_60", "fwd"), "twiddle_inverse_4096_60bit.hex": ("P4096_60", "inv"),
+             "twiddle_forward_4096.hex": ("P4096", "fwd"), "twiddle_inverse_4096.hex": ("P4096", "inv"),
+             "twiddle_forward_1024.hex": ("P1024", "fwd"), "twiddle_inverse_1024.hex": ("P1024", "inv"),
+             "twiddle_forward.hex": ("P256", "fwd"), "twiddle_inverse.hex": ("P256", "inv")}
+    out = {}
+    for name, (tag, kind) in files.items():
+        data = open(os.path.join(REF, "rtl", name), "rb").read()
+        lines = data.decode().splitlines()
+        out[name] = {"tag": tag, "kind": kind, "sha256": hashlib.sha256(data).hexdigest(), "lines": len(lines),
+                     "first": lines[:3], "last": lines[-1]}
+    with open(os.path.join(HERE, "reference_hex_digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("hex digests:", len(out))
+
+
 if __name__ == "__main__":
     for tag in PARAMS:
         gen(tag)
+    hex_digests()

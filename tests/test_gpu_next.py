@@ -1,0 +1,129 @@
+"""GPU tests for the SURVEY.md §8(f) rows: cyclic (RTL-style) product, pointwise product, on-device O(n^2)
+checker, plan-table export against the reference hex format, RoCC-protocol session facade."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PARAMS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available()
+    from tiny_ntt_amd import engine
+    return engine
+
+
+def cyclic_oracle(oracle, a, b, q, omega):
+    A, B = oracle.cg_ntt(a, omega, q), oracle.cg_ntt(b, omega, q)
+    C = np.array([int(x) * int(y) % q for x, y in zip(A, B)], dtype=np.uint64)      # python_poly_mult, test_ntt_poly_mult.py:38-43
+    return oracle.cg_intt(C, omega, q)
+
+
+@pytest.mark.parametrize("tag", ["P4", "P256", "P1024", "P4096", "P4096_60"])
+def test_cyclic_product_matches_rtl_reference_model(eng, oracle, tag):
+    n, q, psi = PARAMS[tag]
+    plan = eng.get_plan(n, q, psi)
+    rng = np.random.default_rng(99)
+    a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
+    a[0] = 0; a[0, :3] = [1, 2, 3]; b[0] = 0; b[0, :2] = [5, 1]                      # chipyard/ntt-test.c KAT
+    for v in ("cg", "cg8", "cg8_padded"):
+        got = plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
+        for r in range(3):
+            assert np.array_equal(got[r], cyclic_oracle(oracle, a[r], b[r], q, plan.omega)), (tag, v, r)
+    if n >= 8:
+        assert list(got[0][:5]) == [5, 11, 17, 3, 0]                                  # no wrap-around: same as the negacyclic KAT
+    # cyclic wrap-around differs from negacyclic: x^(n-1) * x = +1
+    xm = np.zeros(n, dtype=plan.dtype); xm[n - 1] = 1
+    x1 = np.zeros(n, dtype=plan.dtype); x1[1] = 1
+    assert plan.cyclic_poly_mult(xm, x1)[0] == 1 and plan.poly_mult(xm, x1)[0] == q - 1
+    with pytest.raises(eng.TinyNttError, match="only the CG variants"):
+        plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant="fused")
+
+
+@pytest.mark.parametrize("tag", ["P256", "P1024", "P4096_60"])
+def test_pointwise_and_schoolbook_checker(eng, oracle, tag):
+    n, q, psi = PARAMS[tag]
+    plan = eng.get_plan(n, q, psi)
+    rng = np.random.default_rng(5)
+    word = 2 ** (8 * plan.elem_bytes) - 1
+    a = rng.integers(0, q, (4, n), dtype=np.uint64); b = rng.integers(0, q, (4, n), dtype=np.uint64)
+    a[0], b[0] = q - 1, q - 1
+    a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True)                  # unreduced words
+    pw = plan.pointwise_mul(a.astype(plan.dtype), b.astype(plan.dtype)).astype(np.uint64)
+    expect = np.array([[int(x) * int(y) % q for x, y in zip(ra, rb)] for ra, rb in zip(a, b)], dtype=np.uint64)
+    assert np.array_equal(pw, expect)
+    sb = plan.schoolbook(a.astype(plan.dtype), b.astype(plan.dtype)).astype(np.uint64)
+    for r in range(4):
+        assert np.array_equal(sb[r], oracle.schoolbook(a[r], b[r], q)), (tag, r)
+    # the O(n^2) kernel and the NTT kernels agree on device: the reference's --check (benchmark_ntt_60bit.cpp:215-223)
+    assert np.array_equal(sb, plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype)).astype(np.uint64))
+
+
+def test_device_check_like_reference_dash_dash_check(eng):
+    import torch
+    plan = eng.get_plan(*PARAMS["P4096_60"])
+    a = plan.fill_lcg(8, 1, 2); b = plan.fill_lcg(8, 2, 2)
+    assert torch.equal(plan.schoolbook(a, b), plan.poly_mult(a, b))
+
+
+def test_plan_tables_equal_reference_hex_files(eng):
+    import hashlib
+    from tiny_ntt_amd import twiddles
+    with open(os.path.join(GOLDEN, "reference_hex_digests.json")) as f:
+        digests = json.load(f)
+    for name, d in digests.items():
+        if d["kind"] != "fwd":
+            continue
+        n, q, psi = PARAMS[d["tag"]]
+        plan = eng.get_plan(n, q, psi)
+        table = plan.export_table("psi_pow")                                          # what the kernels actually multiply by
+        upper = d["first"][1] != d["first"][1].lower()
+        assert hashlib.sha256(twiddles.format_hex(table, q, uppercase=upper).encode()).hexdigest() == d["sha256"], name
+    n, q, psi = PARAMS["P4096_60"]
+    plan = eng.get_plan(n, q, psi)
+    inv, ninv = twiddles.inverse_table(n, q, psi), pow(n, q - 2, q)
+    assert [int(v) for v in plan.export_table("psi_inv_ninv")] == [x * ninv % q for x in inv]
+    om = plan.export_table("omega_pow")
+    assert len(om) == n // 2 and int(om[1]) == psi * psi % q
+    brv = plan.export_table("psi_brv")
+    assert int(brv[1]) == pow(psi, n // 2, q) and int(brv[2]) == pow(psi, n // 4, q)
+
+
+def test_plan_from_hex_file(eng, tmp_path):
+    from tiny_ntt_amd import twiddles
+    n, q, psi = PARAMS["P1024"]
+    path = tmp_path / "twiddle_forward_1024.hex"
+    twiddles.write_hex(str(path), twiddles.forward_table(n, q, psi), q, uppercase=False)
+    plan = twiddles.plan_from_hex(str(path), q)
+    assert (plan.n, plan.psi) == (n, psi)
+
+
+@pytest.mark.parametrize("mode", ["cyclic", "negacyclic"])
+def test_rocc_session_protocol(eng, oracle, mode):
+    from tiny_ntt_amd import rocc
+    n, q, psi = PARAMS["P4096"]                     # the accelerator's configuration: chipyard/ntt-test.c:21, 32-bit coefficients
+    s = rocc.NttRoccSession(n, q, psi, mode=mode)
+    assert s.rocc(rocc.FUNCT_STATUS) == 0
+    a, b = [1, 2, 3], [5, 1]                        # chipyard/ntt-test.c:91-108
+    c = s.multiply(a, b)
+    assert c[:5] == [5, 11, 17, 3, 0] and not any(c[5:])
+    st = s.rocc(rocc.FUNCT_STATUS)
+    assert st & rocc.STATUS_DONE and not st & rocc.STATUS_BUSY and (st >> 4) & 0xF == rocc.STATE_DONE
+    assert st & rocc.STATUS_FWD_DONE and st & rocc.STATUS_INV_DONE
+    # debug memories expose the forward transforms of A and B (funct 5/6)
+    A = oracle.cg_ntt(np.array(a + [0] * (n - 3), dtype=np.uint64), psi * psi % q, q)
+    assert [s.rocc(rocc.FUNCT_DEBUG_READ_A, i) for i in (0, 1, 777, n - 1)] == [int(A[i]) for i in (0, 1, 777, n - 1)]
+    # addresses wrap to addrWidth bits, data to the coefficient width, unknown funct answers 0
+    s.rocc(rocc.FUNCT_LOAD_A, n + 1, q + 7)
+    assert s._a[1] == 7 and s.rocc(99, 1, 2) == 0
+    rng = np.random.default_rng(3)
+    ra = rng.integers(0, q, n, dtype=np.uint64); rb = rng.integers(0, q, n, dtype=np.uint64)
+    got = np.array(s.multiply(ra, rb), dtype=np.uint64)
+    ref = cyclic_oracle(oracle, ra, rb, q, psi * psi % q) if mode == "cyclic" else oracle.poly_mult(ra, rb, q, psi)
+    assert np.array_equal(got, ref)

@@ -175,6 +175,50 @@ extern "C" tn_status tn_poly_mult_dev(tn_plan* p, const void* a, const void* b, 
   return TN_OK;
 }
 
+extern "C" tn_status tn_cyclic_poly_mult_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant,
+                                             void* stream) {
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_cyclic_poly_mult_dev");
+  if (st) return st;
+  TN_HIP(hipSetDevice(p->device));
+  if (variant == TN_VARIANT_AUTO) variant = TN_VARIANT_CG;
+  CgSel sel;
+  if (!cg_sel(variant, &sel)) return fail(TN_EUNSUPPORTED, "tn_cyclic_poly_mult_dev: only the CG variants implement the untwisted product");
+  TN_HIP(launch_cg(p, CG_CYCLIC_POLYMUL, sel.group, sel.padded, a, b, c, nullptr, batch, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_pointwise_mul_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, void* stream) {
+  if (!p) return fail(TN_EINVAL, "tn_pointwise_mul_dev: plan is NULL");
+  if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_pointwise_mul_dev: batch too large");
+  if (batch && (!a || !b || !c)) return fail(TN_EINVAL, "tn_pointwise_mul_dev: NULL buffer");
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(launch_pointwise(p, a, b, c, batch, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_schoolbook_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, void* stream) {
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_schoolbook_dev");
+  if (st) return st;
+  TN_HIP(hipSetDevice(p->device));
+  TN_HIP(launch_schoolbook(p, a, b, c, batch, pick_stream(p, stream)));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out) {
+  if (!p || !host_out) return fail(TN_EINVAL, "tn_plan_export_table: NULL argument");
+  const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv};
+  if (which < 0 || which > 5) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
+  const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
+  TN_HIP(hipSetDevice(p->device));
+  // device records are {w, w'} pairs; only the constants w are exported, as uint64
+  std::vector<unsigned char> raw(count * 2 * (size_t)p->elem_bytes);
+  TN_HIP(hipMemcpy(raw.data(), tabs[which], raw.size(), hipMemcpyDeviceToHost));
+  uint64_t* out = (uint64_t*)host_out;
+  for (size_t i = 0; i < count; ++i)
+    out[i] = p->elem_bytes == 8 ? ((const Tw64*)raw.data())[i].w : ((const Tw32*)raw.data())[i].w;
+  return TN_OK;
+}
+
 static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t batch, tn_variant variant, void* stream,
                          void* trace, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);

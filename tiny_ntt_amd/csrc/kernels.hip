@@ -335,10 +335,13 @@ cg_kernel(PlanView<E> pv, int mode, const E* __restrict__ a, const E* __restrict
       E* r = cg_stages<E, GROUP, PAD>(p0, p1, pv.omega_inv_pow, n, logn, ar, nullptr);
       for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[off + i] = mul_tw(r[M::at(i)], ar.ninv, ar.q);   // :74-75
     } else {                                                       // nwc_poly_mult: cg_ntt.py:78-92
-      cg_load_brv<E, GROUP, PAD>(p0, a + off, pv.psi_pow, n, logn, ar);                 // :82
+      // CG_CYCLIC_POLYMUL: the same chain without twist/untwist = python_poly_mult
+      // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
+      const typename TwOf<E>::type* twist = (mode == CG_CYCLIC_POLYMUL) ? nullptr : pv.psi_pow;
+      cg_load_brv<E, GROUP, PAD>(p0, a + off, twist, n, logn, ar);                      // :82
       E* ra = cg_stages<E, GROUP, PAD>(p0, p1, pv.omega_pow, n, logn, ar, nullptr);     // :86
       E* f1 = (ra == p0) ? p1 : p0;
-      cg_load_brv<E, GROUP, PAD>(p2, b + off, pv.psi_pow, n, logn, ar);                 // :83
+      cg_load_brv<E, GROUP, PAD>(p2, b + off, twist, n, logn, ar);                      // :83
       E* rb = cg_stages<E, GROUP, PAD>(p2, f1, pv.omega_pow, n, logn, ar, nullptr);     // :87
       E* f2 = (rb == p2) ? f1 : p2;
       for (u32 i = threadIdx.x; i < n; i += blockDim.x)                                 // :88, stored bit-reversed for :73
@@ -346,7 +349,7 @@ cg_kernel(PlanView<E> pv, int mode, const E* __restrict__ a, const E* __restrict
       __syncthreads();
       E* rc = cg_stages<E, GROUP, PAD>(f2, ra, pv.omega_inv_pow, n, logn, ar, nullptr); // :90 (:72-73)
       for (u32 i = threadIdx.x; i < n; i += blockDim.x)
-        out[off + i] = mul_tw(rc[M::at(i)], pv.psi_inv_ninv[i], ar.q);                  // :74-75 and :91-92 in one exact product
+        out[off + i] = mul_tw(rc[M::at(i)], twist ? pv.psi_inv_ninv[i] : ar.ninv, ar.q); // :74-75 and :91-92 in one exact product
     }
     __syncthreads();
   }
@@ -393,6 +396,79 @@ hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const v
 }
 
 const char* cg_kernel_name(const tn_plan*, int, bool) { return "cg_kernel"; }
+
+// ============================================================================
+// Elementwise product and the O(n^2) direct product (on-device checker)
+// ============================================================================
+// pointwise_mul (benchmark_ntt_60bit.cpp:142-146; cg_ntt.py:88): c[i] = a[i] * b[i] mod q
+template <typename E>
+__global__ void pointwise_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ c, size_t total) {
+  const Arith<E> ar = pv.ar;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    c[i] = mulmod_barrett(mul_tw(a[i], ar.one, ar.q), mul_tw(b[i], ar.one, ar.q), ar.q, ar.mu, ar.k);
+}
+
+// negacyclic_mul_reference (benchmark_ntt_60bit.cpp:167-180; test_cg_ntt.py:11-21; the
+// benchmark_simple family): c[k] = sum_{i<=k} a[i] b[k-i] - sum_{i>k} a[i] b[n+k-i]  (mod q).
+// One workgroup per (row, 256 output coefficients); operands staged in LDS.
+template <typename E>
+__global__ void __launch_bounds__(256)
+schoolbook_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ c, u32 batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  const u32 n = pv.n;
+  const Arith<E> ar = pv.ar;
+  E* sa = reinterpret_cast<E*>(tn_smem);
+  E* sb = sa + n;
+  const u32 chunks = (n + 255) / 256;
+  for (u32 w = blockIdx.x; w < batch * chunks; w += gridDim.x) {
+    const u32 row = w / chunks, k = (w % chunks) * 256 + threadIdx.x;
+    const size_t off = (size_t)row * n;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+      sa[i] = mul_tw(a[off + i], ar.one, ar.q);
+      sb[i] = mul_tw(b[off + i], ar.one, ar.q);
+    }
+    __syncthreads();
+    if (k < n) {
+      E acc = 0;
+      for (u32 i = 0; i < n; ++i) {
+        const E t = mulmod_barrett(sa[i], sb[(k - i) & (n - 1)], ar.q, ar.mu, ar.k);
+        if (i <= k) acc = csub((E)(acc + t), ar.q);
+        else acc = acc >= t ? (E)(acc - t) : (E)(acc + (ar.q - t));
+      }
+      c[off + k] = acc;
+    }
+  }
+}
+
+template <typename E>
+static hipError_t launch_aux_e(const tn_plan* p, int what, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  if (what == 0) {
+    const size_t total = batch * p->n;
+    const u32 blocks = (u32)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pointwise_kernel<E>, dim3(blocks), dim3(256), 0, s, make_view<E>(p), (const E*)a, (const E*)b, (E*)c, total);
+  } else {
+    const size_t lds_bytes = (size_t)2 * p->n * sizeof(E);
+    auto kern = schoolbook_kernel<E>;
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    const size_t work = batch * ((p->n + 255) / 256);
+    const u32 blocks = (u32)(work < 65536 ? work : 65536);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, make_view<E>(p), (const E*)a, (const E*)b, (E*)c, (u32)batch);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pointwise(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  return p->elem_bytes == 8 ? launch_aux_e<u64>(p, 0, a, b, c, batch, s) : launch_aux_e<u32>(p, 0, a, b, c, batch, s);
+}
+hipError_t launch_schoolbook(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  return p->elem_bytes == 8 ? launch_aux_e<u64>(p, 1, a, b, c, batch, s) : launch_aux_e<u32>(p, 1, a, b, c, batch, s);
+}
 
 // ============================================================================
 // Synthetic inputs + digest (reference benchmark conventions)

@@ -32,7 +32,7 @@ struct tn_plan {
 
 namespace tn {
 
-enum CgMode { CG_NTT_FWD = 0, CG_NTT_INV = 1, CG_POLYMUL = 2, CG_TWIST_FWD = 3 };
+enum CgMode { CG_NTT_FWD = 0, CG_NTT_INV = 1, CG_POLYMUL = 2, CG_TWIST_FWD = 3, CG_CYCLIC_POLYMUL = 4 };
 
 template <typename E> struct PlanView {
   typedef typename TwOf<E>::type Tw;
@@ -67,6 +67,8 @@ const char* cg_kernel_name(const tn_plan* p, int group, bool padded);
 hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
 hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
                      void* trace, size_t batch, hipStream_t s);
+hipError_t launch_pointwise(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
+hipError_t launch_schoolbook(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
 hipError_t launch_fill_lcg(const tn_plan* p, void* dst, size_t batch, u64 seed0, u64 stride, hipStream_t s);
 hipError_t launch_checksum(const tn_plan* p, const void* src, u64* out, size_t batch, hipStream_t s);
 

@@ -33,7 +33,8 @@ PLAN_FORCE_CANONICAL = 1
 EXPORTED_SYMBOLS = (
     "tn_plan_create", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
     "tn_plan_elem_bytes", "tn_plan_device", "tn_plan_has_fused", "tn_plan_is_lazy",
-    "tn_poly_mult_dev", "tn_poly_mult_host", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
+    "tn_poly_mult_dev", "tn_poly_mult_host", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
+    "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
     "tn_ntt_forward_host", "tn_ntt_inverse_host", "tn_ntt_forward_trace_host", "tn_twisted_ntt_forward_dev",
     "tn_fill_lcg_dev", "tn_checksum_rows_dev", "tn_plan_synchronize", "tn_time_poly_mult_dev",
     "tn_kernel_name", "tn_last_error", "tn_status_string", "tn_version",
@@ -76,6 +77,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         getattr(lib, name).restype = res
     lib.tn_poly_mult_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
     lib.tn_poly_mult_host.argtypes = [vp, vp, vp, vp, sz, ci]
+    lib.tn_cyclic_poly_mult_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+    lib.tn_pointwise_mul_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tn_schoolbook_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tn_plan_export_table.argtypes = [vp, ci, vp]
     for name in ("tn_ntt_forward_dev", "tn_ntt_inverse_dev", "tn_twisted_ntt_forward_dev"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz, ci, vp]
     for name in ("tn_ntt_forward_host", "tn_ntt_inverse_host"):
@@ -217,6 +222,44 @@ class Plan:
         hc = np.empty_like(ha)
         _check(self._lib, self._lib.tn_poly_mult_host(self._h, ha.ctypes.data, hb.ctypes.data, hc.ctypes.data, ha.shape[0], v))
         return hc[0] if squeeze else hc
+
+    def _binary_dev(self, fn, a, b, out, stream, *extra):
+        """Shared marshalling of the device-only binary operators; numpy inputs are staged through torch."""
+        import torch
+        host = not _is_torch(a)
+        squeeze = host and np.ndim(a) == 1
+        if host:
+            a, b = self.to_device(a), self.to_device(b)
+        rows = self._dev_rows(a, "a")
+        if self._dev_rows(b, "b") != rows:
+            raise ValueError(f"Expected {self.n} coefficients")
+        c = out if out is not None else torch.empty_like(a)
+        _check(self._lib, fn(self._h, a.data_ptr(), b.data_ptr(), c.data_ptr(), rows, *extra, self._stream_ptr(stream)))
+        if host:
+            res = self.to_host(c)
+            return res[0] if squeeze else res
+        return c
+
+    def cyclic_poly_mult(self, a, b, variant="cg", out=None, stream=None):
+        """Untwisted product forward->pointwise->inverse: python_poly_mult (test_ntt_poly_mult.py:38-43)."""
+        return self._binary_dev(self._lib.tn_cyclic_poly_mult_dev, a, b, out, stream, _variant(variant))
+
+    def pointwise_mul(self, a, b, out=None, stream=None):
+        """c[i] = a[i]*b[i] mod q (cg_ntt.py:88; benchmark_ntt_60bit.cpp:142-146)."""
+        return self._binary_dev(self._lib.tn_pointwise_mul_dev, a, b, out, stream)
+
+    def schoolbook(self, a, b, out=None, stream=None):
+        """O(n^2) direct negacyclic product on device (benchmark_ntt_60bit.cpp:167-180): independent checker."""
+        return self._binary_dev(self._lib.tn_schoolbook_dev, a, b, out, stream)
+
+    TABLES = {"psi_pow": 0, "psi_inv_ninv": 1, "omega_pow": 2, "omega_inv_pow": 3, "psi_brv": 4, "psi_inv_brv": 5}
+
+    def export_table(self, which) -> np.ndarray:
+        """One of the plan's device tables as uint64 values (see tn_plan_export_table)."""
+        w = self.TABLES[which] if isinstance(which, str) else int(which)
+        out = np.empty(self.n // 2 if w in (2, 3) else self.n, dtype=np.uint64)
+        _check(self._lib, self._lib.tn_plan_export_table(self._h, w, out.ctypes.data))
+        return out
 
     def _ntt(self, fn_dev, fn_host, x, variant, out, stream):
         v = _variant(variant)

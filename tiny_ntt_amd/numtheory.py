@@ -72,3 +72,31 @@ def find_psi(n: int, q: int) -> int:
     if best is None:
         raise ValueError("no primitive 2n-th root found")
     return best
+
+
+def barrett_constants(q: int):
+    """(k, mu): k = bitlen(q), mu = floor(2^(2k) / q) — scripts/precompute_constants.py:30-55, the
+    constants of rtl/barrett_reduction.v:6-7 (k=23, mu=8396807 for q=8380417)."""
+    k = q.bit_length()
+    return k, (1 << (2 * k)) // q
+
+
+def montgomery_constants(q: int):
+    """(k, R, R^-1 mod q, q' = -q^-1 mod R) with R = 2^k — scripts/precompute_constants.py:58-111."""
+    k = q.bit_length()
+    R = 1 << k
+    r_inv = pow(R, -1, q)
+    q_prime = (-pow(q, -1, R)) % R
+    return k, R, r_inv, q_prime
+
+
+def barrett_reduce(product: int, q: int) -> int:
+    """The reference recipe on Python ints (precompute_constants.py:38-46, self-test :145-172), with the
+    second conditional subtraction kept."""
+    k, mu = barrett_constants(q)
+    q1 = product >> (k - 1)
+    q2 = (q1 * mu) >> (k + 1)
+    r = product - q2 * q
+    while r >= q:
+        r -= q
+    return r
