@@ -125,12 +125,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 flow on a 1-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        tdist.init_process_group("nccl")
-    dev = torch.device("cuda", local_rank)
+        tdist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    plan = engine.Plan(N_COEFF, Q, PSI, device=local_rank)
+    plan = engine.Plan(N_COEFF, Q, PSI, device=dev_index)
     rows = args.rows
     first_row = rank * rows                                    # this rank's block of the global batch
     a = plan.fill_lcg(rows, 2 * first_row + 1, 2)              # global row r: make_poly(2r+1), make_poly(2r+2)
@@ -157,11 +161,11 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = tdist.max_over_ranks(elapsed, dev)
+    elapsed = tdist.max_over_ranks(elapsed, red_dev)
 
     # dominant kernel: mean launch duration with HIP events on the stream it runs on
     kernel_ms = plan.time_poly_mult(a, b, c, max(args.steps, 5), args.variant)
-    kernel_ms = tdist.max_over_ranks(kernel_ms, dev)
+    kernel_ms = tdist.max_over_ranks(kernel_ms, red_dev)
     achieved = rows * BYTES_PER_PRODUCT / (kernel_ms * 1e-3) / 1e9
 
     traffic = None

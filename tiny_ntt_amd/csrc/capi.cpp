@@ -151,7 +151,7 @@ static bool cg_sel(tn_variant v, CgSel* s) {
 
 static tn_status check_ptrs(const tn_plan* p, const void* a, const void* b, const void* c, size_t batch, const char* fn) {
   if (!p) return fail(TN_EINVAL, std::string(fn) + ": plan is NULL");
-  if (batch > 0xffffffffull) return fail(TN_EINVAL, std::string(fn) + ": batch too large for one call");
+  if (batch > 0x7fffffffull) return fail(TN_EINVAL, std::string(fn) + ": batch too large for one call (max 2^31 - 1 rows)");
   if (batch && (!a || !b || !c)) return fail(TN_EINVAL, std::string(fn) + ": NULL buffer");
   if (batch && (c == a || c == b)) return fail(TN_EINVAL, std::string(fn) + ": output must not alias an input");
   return TN_OK;
