@@ -122,20 +122,24 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 
 template <typename E, int LOGN, int LPT, bool LAZY>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), TN_FUSED_MIN_WAVES)
-polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ c, u32 batch) {
+polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
+                     const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
+                     E* __restrict__ c, u32 batch) {
+  // The twiddle tables are separate __restrict__ kernel arguments (not fields of a struct) so the
+  // compiler can prove the stores to c never alias them: wave-uniform twiddle loads then become
+  // scalar loads (s_load_dwordx4) instead of vector loads that every wave would wait on.
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
   E* lds = reinterpret_cast<E*>(tn_smem);
   typedef typename TwOf<E>::type Tw;
   const u32 tau = threadIdx.x;
-  const Arith<E> ar = pv.ar;
   // twiddles of the lane-dependent middle phases: staged once per (persistent) workgroup in LDS
   Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0));
   Tw* lds_inv = lds_fwd + Cfg::lds_tw_count();
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) {
-    lds_fwd[i] = pv.psi_brv[Cfg::lds_tw_lo() + i];
-    lds_inv[i] = pv.psi_inv_brv[Cfg::lds_tw_lo() + i];
+    lds_fwd[i] = tab_fwd[Cfg::lds_tw_lo() + i];
+    lds_inv[i] = tab_inv[Cfg::lds_tw_lo() + i];
   }
   __syncthreads();
   // Persistent workgroup: rows blockIdx.x, blockIdx.x + gridDim.x, ...  The next row's first
@@ -153,7 +157,7 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
     for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tau, r);
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(xa[r], ar);
-    forward_all<E, Cfg, Pol>(xa, tau, pv.psi_brv, lds_fwd, ar, lds);
+    forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds);
 #if TN_PARK_LDS
     // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
     // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
@@ -163,17 +167,17 @@ polymul_fused_kernel(PlanView<E> pv, const E* __restrict__ a, const E* __restric
 #endif
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(xb[r], ar);
-    forward_all<E, Cfg, Pol>(xb, tau, pv.psi_brv, lds_fwd, ar, lds);
+    forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds);
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
-    tw_prefetch<E, Cfg>(pre, tau, pv.psi_inv_brv);
+    tw_prefetch<E, Cfg>(pre, tau, tab_inv);
 #if TN_PARK_LDS
 #pragma unroll
     for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
 #endif
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     const u32 next = row + gridDim.x;
-    const TwRefs<E> twi = {pv.psi_inv_brv, lds_inv, pre};
+    const TwRefs<E> twi = {tab_inv, lds_inv, pre};
     inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {
       if (next < batch) {              // next row's first operand -> the registers that held b
 #pragma unroll
@@ -222,7 +226,9 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
   const u32 grid = (u32)(batch < resident ? batch : resident);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, make_view<E>(p), (const E*)a, (const E*)b, (E*)c, (u32)batch);
+  const PlanView<E> pv = make_view<E>(p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, pv.ar, pv.psi_brv, pv.psi_inv_brv, (const E*)a, (const E*)b,
+                     (E*)c, (u32)batch);
   return hipGetLastError();
 }
 
