@@ -21,6 +21,9 @@
 #ifndef TN_ABL_NO_GLOBAL
 #define TN_ABL_NO_GLOBAL 0       // timing ablation: operands synthesised in registers instead of loaded from HBM
 #endif
+#ifndef TN_STORE_AT_TOP
+#define TN_STORE_AT_TOP 1        // 1: row k's result is stored at the top of iteration k+1 (see the kernel's comment)
+#endif
 #ifndef TN_NT_STREAM
 #define TN_NT_STREAM 1           // 1: non-temporal loads/stores for the streamed operands a, b, c
 #endif
@@ -120,6 +123,19 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 #endif
 }
 
+template <typename E, typename Cfg>
+__device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, const E (&x)[Cfg::R]) {
+  const size_t off = (size_t)row << Cfg::LOGN;
+#pragma unroll
+  for (int r = 0; r < Cfg::R; ++r) {
+#if TN_NT_STREAM
+    __builtin_nontemporal_store(x[r], c + off + Cfg::jidx(0, tau, r));
+#else
+    c[off + Cfg::jidx(0, tau, r)] = x[r];
+#endif
+  }
+}
+
 template <typename E, int LOGN, int LPT, bool LAZY>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), TN_FUSED_MIN_WAVES)
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
@@ -150,9 +166,20 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   u32 row = blockIdx.x;
   if (row < batch) {
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = ld_operand<E, Cfg>(a, row, tau, r);
+    for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, row, tau, r);
   }
+  // The stores of row k are issued at the TOP of iteration k+1 (software-pipelined): vector-memory
+  // operations retire in order and the compiler drains them all at the loop back-edge, so stores
+  // issued at the bottom would expose their full latency there on every row.  Issued at the top,
+  // the only operations in flight at the back-edge are the prefetch loads, which are needed anyway.
+  u32 prev = 0;
+  bool have_c = false;
   for (; row < batch; row += gridDim.x) {
+#if TN_STORE_AT_TOP
+    if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
+#endif
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = xb[r];            // this row's a (prefetched during the previous inverse)
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tau, r);
 #pragma unroll
@@ -184,18 +211,14 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
         for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tau, r);
       }
     });
-    const size_t off = (size_t)row << LOGN;
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) {
-#if TN_NT_STREAM
-      __builtin_nontemporal_store(xa[r], c + off + Cfg::jidx(0, tau, r));
+#if TN_STORE_AT_TOP
+    prev = row;
+    have_c = true;
 #else
-      c[off + Cfg::jidx(0, tau, r)] = xa[r];
+    st_result<E, Cfg>(c, row, tau, xa);
 #endif
-    }
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = xb[r];
   }
+  if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
 }
 
 // log2(n) -> coefficients per thread (log2)
