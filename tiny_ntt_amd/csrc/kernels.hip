@@ -172,18 +172,28 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // operations retire in order and the compiler drains them all at the loop back-edge, so stores
   // issued at the bottom would expose their full latency there on every row.  Issued at the top,
   // the only operations in flight at the back-edge are the prefetch loads, which are needed anyway.
-  u32 prev = 0;
+  // (first iteration: nothing to store yet -> the zero-initialised registers are written to this
+  //  row's own slot, which the same thread overwrites with the real result one iteration later;
+  //  keeping the store unconditional keeps the loop top branch-free so the ordering below holds)
+  u32 prev = row;
   bool have_c = false;
+#pragma unroll
+  for (int r = 0; r < Cfg::R; ++r) xa[r] = 0;
   for (; row < batch; row += gridDim.x) {
+    // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
+    // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
+    E xn[Cfg::R];
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xn[r] = Pol::load(xb[r], ar);
+    sched_fence();
 #if TN_STORE_AT_TOP
-    if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
+    st_result<E, Cfg>(c, prev, tau, xa);
 #endif
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = xb[r];            // this row's a (prefetched during the previous inverse)
-#pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tau, r);
+    sched_fence();
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xa[r] = Pol::load(xa[r], ar);
+    for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
     forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds);
 #if TN_PARK_LDS
     // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
