@@ -118,3 +118,17 @@ def test_fold_bounds(emu):
     for x in [0, 1, 2 ** 23, 2 ** 32 - 1, 2 ** 31] + [rnd.randrange(2 ** 32) for _ in range(2000)]:
         r = emu.lib.emu_fold32(x, q23)
         assert r % q23 == x % q23 and r < 2 * q23
+
+
+@pytest.mark.parametrize("n", [512, 2048])
+@pytest.mark.parametrize("q", [8380417, 1152921504606830593])
+def test_fused_emulation_other_sizes(emu, oracle, n, q):
+    """n = 512 / 2048 (8 coefficients per thread, partial last phase): psi found for each (n, q)."""
+    from tiny_ntt_amd import numtheory
+    psi = numtheory.find_psi(n, q)
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, q, (4, n), dtype=np.uint64); b = rng.integers(0, q, (4, n), dtype=np.uint64)
+    a[0], b[0] = q - 1, q - 1
+    ref = oracle.poly_mult(a, b, q, psi)
+    for canonical in (False, True):
+        assert np.array_equal(emu.fused(n, q, psi, a, b, canonical=canonical), ref)

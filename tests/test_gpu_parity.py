@@ -128,7 +128,7 @@ def test_generic_moduli_run_canonical(eng, oracle):
 
 
 def test_sizes_without_a_fused_kernel_use_cg(eng, oracle):
-    for n in (8, 16, 64, 128, 512, 2048):
+    for n in (8, 16, 64, 128):
         q = 8380417
         if (q - 1) % (2 * n):
             continue
@@ -308,3 +308,71 @@ def test_device_buffers_streams_and_aliasing(eng):
     with pytest.raises(eng.TinyNttError, match="only the CG variants"):
         plan.ntt_forward(a, variant="fused")
     assert plan.kernel_name("fused") == "polymul_fused_kernel" and plan.kernel_name("cg8") == "cg_kernel"
+
+
+def test_config4_total_batch_1M_rows_on_one_gpu_max_size(eng, oracle):
+    """BASELINE configs[3]'s whole batch (2^20 pairs, 96 GiB for a, b, c) on a single 288 GB MI355X: the largest
+    size in BASELINE.json; exercises > 4 GiB offsets and the persistent grid's tail.  Size-independent checks:
+    reference checksum on row 0, sampled rows vs the oracle, slab re-computation, commutativity on a slab."""
+    import torch
+    n, q, psi = PARAMS["P4096_60"]
+    rows = 1 << 20
+    free, _total = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip(f"needs ~96 GiB of free HBM, {free / 2 ** 30:.0f} GiB available")
+    plan = plan_for(eng, "P4096_60")
+    a = plan.fill_lcg(rows, 1, 2); b = plan.fill_lcg(rows, 2, 2)
+    c = plan.poly_mult(a, b)
+    sums = plan.checksum_rows(c[:4])
+    assert int(sums[0]) == REF_CHECKSUMS["P4096_60"][1]
+    idx = [0, 1, 65535, 65536, 524287, 524288, rows - 2, rows - 1]
+    ha, hb, hc = plan.to_host(a[idx]), plan.to_host(b[idx]), plan.to_host(c[idx])
+    assert np.array_equal(ha[0], oracle.make_poly(1, n, q)) and np.array_equal(ha[-1], oracle.make_poly(2 * (rows - 1) + 1, n, q))
+    assert np.array_equal(hc, oracle.poly_mult(ha, hb, q, psi))
+    for start in (0, 3 * 65536 + 17, rows - 300):                    # slabs recomputed on their own == the big launch
+        sl = slice(start, start + 300)
+        assert torch.equal(plan.poly_mult(a[sl].contiguous(), b[sl].contiguous()), c[sl])
+    assert torch.equal(plan.poly_mult(b[-4096:].contiguous(), a[-4096:].contiguous()), c[-4096:])
+    del a, b, c
+    torch.cuda.empty_cache()
+
+
+def test_two_host_threads_with_their_own_plans(eng, oracle):
+    """Threading contract of include/tinyntt.h: distinct plans may be used from distinct host threads."""
+    import threading
+    results, errors = {}, []
+
+    def work(tag, seed):
+        try:
+            n, q, psi = PARAMS[tag]
+            plan = eng.Plan(n, q, psi)                 # private plan, private stream
+            rng = np.random.default_rng(seed)
+            a = rng.integers(0, q, (32, n), dtype=np.uint64); b = rng.integers(0, q, (32, n), dtype=np.uint64)
+            for _ in range(5):
+                got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype)).astype(np.uint64)
+            results[tag] = (got, a, b)
+            plan.close()
+        except Exception as e:                         # pragma: no cover
+            errors.append((tag, e))
+
+    ts = [threading.Thread(target=work, args=(t, i)) for i, t in enumerate(("P4096_60", "P1024", "P4096", "P256"))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors
+    for tag, (got, a, b) in results.items():
+        n, q, psi = PARAMS[tag]
+        assert np.array_equal(got, oracle.poly_mult(a, b, q, psi)), tag
+
+
+@pytest.mark.parametrize("n", [512, 2048])
+@pytest.mark.parametrize("q", [8380417, 1152921504606830593])
+def test_fused_kernels_for_n512_n2048(eng, oracle, n, q):
+    from tiny_ntt_amd import numtheory
+    psi = numtheory.find_psi(n, q)
+    plan = eng.get_plan(n, q, psi)
+    assert plan.has_fused and plan.is_lazy
+    rng = np.random.default_rng(n + 1)
+    a = rng.integers(0, q, (300, n), dtype=np.uint64); b = rng.integers(0, q, (300, n), dtype=np.uint64)
+    a[0], b[0] = q - 1, q - 1
+    ref = oracle.poly_mult(a, b, q, psi)
+    for v in variants_of(plan):
+        assert np.array_equal(plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64), ref), (n, q, v)

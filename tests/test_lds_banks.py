@@ -97,7 +97,7 @@ def test_bench_config_transposes_are_bank_conflict_free(probe):
 
 
 def test_layouts_are_injective_and_wave_private_where_claimed(probe):
-    for logn, eb in ((12, 8), (12, 4), (10, 4), (10, 8), (8, 4), (8, 8)):
+    for logn, eb in ((12, 8), (12, 4), (11, 8), (11, 4), (10, 4), (10, 8), (9, 8), (9, 4), (8, 4), (8, 8)):
         cfg = Cfg(probe, logn, eb)
         n = 1 << logn
         for ex in range(cfg.phases - 1):
@@ -118,7 +118,7 @@ def test_layouts_are_injective_and_wave_private_where_claimed(probe):
 
 def test_other_configs_conflict_report(probe):
     # padded layouts of the other (non-benchmark) configurations: bounded but not tuned
-    for logn, eb in ((12, 4), (10, 4), (10, 8), (8, 4), (8, 8)):
+    for logn, eb in ((12, 4), (11, 8), (11, 4), (10, 4), (10, 8), (9, 8), (9, 4), (8, 4), (8, 8)):
         cfg = Cfg(probe, logn, eb)
         for key, (w, r) in worst_degrees(cfg).items():
             assert r <= 8 and w <= 8, (logn, eb, key, w, r)      # n=256/u32 has an 8-way store in one transpose: known, not tuned

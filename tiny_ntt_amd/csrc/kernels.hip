@@ -137,7 +137,7 @@ __device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, c
 }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
-__global__ void __launch_bounds__((1 << (LOGN - LPT)), TN_FUSED_MIN_WAVES)
+__global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))   // 16 coeff/thread shapes need > 128 VGPRs
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
                      const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
                      E* __restrict__ c, u32 batch) {
@@ -235,7 +235,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 static int fused_lpt(u32 logn) {
   switch (logn) {
     case 8: return 2;
+    case 9: return 3;
     case 10: return 4;
+    case 11: return 3;
     case 12: return TN_FUSED_LPT12;
     default: return 0;
   }
@@ -269,7 +271,9 @@ template <typename E, bool LAZY>
 static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
   switch (p->logn) {
     case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s);
+    case 9: return launch_fused_t<E, 9, 3, LAZY>(p, a, b, c, batch, s);
     case 10: return launch_fused_t<E, 10, 4, LAZY>(p, a, b, c, batch, s);
+    case 11: return launch_fused_t<E, 11, 3, LAZY>(p, a, b, c, batch, s);
     case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s);
     default: return hipErrorInvalidValue;
   }
