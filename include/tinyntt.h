@@ -104,7 +104,8 @@ tn_status tn_poly_mult_host(tn_plan *plan, const void *a, const void *b, void *c
  * tn_ntt_forward_*  replaces cg_ntt(a_prime, omega_n, modulus)  (cg_ntt.py:29-65),
  *                   cg_ntt_8butterfly (cg_ntt_8butterfly.py:41-97) with TN_VARIANT_CG8.
  * tn_ntt_inverse_*  replaces cg_intt(A, omega_n, modulus)       (cg_ntt.py:68-75).
- * Only the CG variants implement these (AUTO selects CG).
+ * TN_VARIANT_AUTO / FUSED: register-tiled kernel (merged transform + one extra LDS transpose for natural order);
+ * CG variants: the reference's stage sweep.  Identical results.
  */
 tn_status tn_ntt_forward_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
 tn_status tn_ntt_inverse_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
@@ -114,7 +115,8 @@ tn_status tn_ntt_inverse_host(tn_plan *plan, const void *in, void *out, size_t b
 /*
  * Forward transform of ONE polynomial that also returns every stage's output:
  * trace is [log2 n][n] elements, row s-1 = the list `A` after stage s — the
- * data cg_ntt(..., verbose=True) prints 16-at-a-time (cg_ntt.py:60-62).
+ * data cg_ntt(..., verbose=True) prints 16-at-a-time (cg_ntt.py:60-62).  CG variants only (AUTO = CG here):
+ * the stages observed are the reference's constant-geometry stages.
  */
 tn_status tn_ntt_forward_trace_host(tn_plan *plan, const void *in, void *out, void *trace, tn_variant variant);
 
@@ -145,7 +147,7 @@ tn_status tn_schoolbook_dev(tn_plan *plan, const void *a, const void *b, void *c
 /*
  * Copy one of the plan's constant tables to the host as uint64_t values (the constants only,
  * without their Barrett factors).  which: 0 psi^i [n] (= rtl/twiddle_forward*.hex), 1 psi^-i * n^-1 [n],
- * 2 omega^j [n/2], 3 omega^-j [n/2], 4 psi^brv(i) [n], 5 psi^-brv(i) [n].
+ * 2 omega^j [n/2], 3 omega^-j [n/2], 4 psi^brv(i) [n], 5 psi^-brv(i) [n], 6 psi^-i [n] (= rtl/twiddle_inverse*.hex).
  */
 tn_status tn_plan_export_table(tn_plan *plan, int which, void *host_out);
 

@@ -161,6 +161,7 @@ class Emu:
         L.emu_fused_poly_mult.argtypes = [u32, u64, u64, ci, P64, P64, P64, sz]
         L.emu_is_lazy.argtypes = [u32, u64, u64]
         L.emu_cg.argtypes = [u32, u64, u64, ci, P64, P64, P64, P64]
+        L.emu_fused_ntt.argtypes = [u32, u64, u64, ci, ci, P64, P64]
         L.emu_mul_tw64.argtypes = [u64, u64, u64]; L.emu_mul_tw64.restype = u64
         L.emu_mul_tw64_lazy.argtypes = [u64, u64, u64]; L.emu_mul_tw64_lazy.restype = u64
         L.emu_mul_tw32.argtypes = [u32, u32, u32]; L.emu_mul_tw32.restype = u32
@@ -176,6 +177,14 @@ class Emu:
         rc = self.lib.emu_fused_poly_mult(n, q, psi, int(canonical), p64(a2), p64(b2), p64(c), a2.shape[0])
         assert rc == 0, rc
         return c.reshape(a.shape)
+
+    def fused_ntt(self, n, q, psi, mode, x, canonical=False):
+        """mode 0: twist + forward, 1: cg_ntt, 2: cg_intt — register-tiled standalone transforms (natural order)."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        out = np.empty_like(x)
+        rc = self.lib.emu_fused_ntt(n, q, psi, int(canonical), mode, p64(x), p64(out))
+        assert rc == 0, rc
+        return out
 
     def cg(self, n, q, psi, mode, a, b=None, trace=False):
         a = np.ascontiguousarray(a, dtype=np.uint64)

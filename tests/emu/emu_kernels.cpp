@@ -78,6 +78,68 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
   return 0;
 }
 
+// Same steps as ntt_fused_kernel (kernels.hip), one emulated thread at a time.
+template <typename E, int LOGN, int LPT, bool LAZY>
+int fused_ntt_emu(const HostTables& t, int mode, const u64* in, u64* out) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  typedef Policy<E, LAZY> Pol;
+  typedef typename TwOf<E>::type Tw;
+  const Arith<E> ar = h_make_arith<E>(t);
+  const std::vector<Tw> tab = h_tw_table<E>(mode == 2 ? t.psi_inv_brv : t.psi_brv, t.q);
+  const std::vector<Tw> twist = h_tw_table<E>(mode == 1 ? t.psi_inv_pow : t.psi_pow, t.q);
+  std::vector<Tw> lds_tab(tab.begin() + Cfg::lds_tw_lo(), tab.begin() + Cfg::lds_tw_hi());
+  std::vector<E> lds(Cfg::lds_elems());
+  struct Regs { E x[Cfg::R]; };
+  struct Pre { Tw t[Cfg::NPRE]; };
+  std::vector<Regs> x(Cfg::THREADS);
+  std::vector<Pre> pre(Cfg::THREADS);
+  constexpr int LAST = Cfg::PHASES - 1;
+  const u32 T = Cfg::THREADS;
+  for (u32 tau = 0; tau < T; ++tau) tw_prefetch<E, Cfg>(pre[tau].t, tau, tab.data());
+  if (mode == 2) {
+    for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))] = Pol::load((E)in[Cfg::jidx(0, tau, r)], ar);
+    for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) x[tau].x[r] = lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))];
+    static_for<0, Cfg::PHASES>([&](auto i_) {
+      constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
+      for (u32 tau = 0; tau < T; ++tau) { const TwRefs<E> tw = {tab.data(), lds_tab.data(), pre[tau].t}; inv_phase<E, Cfg, Pol, p>(x[tau].x, tau, tw, ar); }
+      if constexpr (p > 0) {
+        for (u32 tau = 0; tau < T; ++tau) ex_store<E, Cfg, p - 1, p>(x[tau].x, tau, lds.data());
+        for (u32 tau = 0; tau < T; ++tau) ex_load<E, Cfg, p - 1, p - 1>(x[tau].x, tau, lds.data());
+      }
+    });
+    for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) { const u32 j = Cfg::jidx(0, tau, r); out[j] = mul_tw(x[tau].x[r], twist[j], ar.q); }
+    return 0;
+  }
+  for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) {
+    const u32 j = Cfg::jidx(0, tau, r);
+    x[tau].x[r] = mode == 1 ? Pol::load(mul_tw_lazy((E)in[j], twist[j], ar.q), ar) : Pol::load((E)in[j], ar);
+  }
+  static_for<0, Cfg::PHASES>([&](auto p_) {
+    constexpr int p = decltype(p_)::value;
+    for (u32 tau = 0; tau < T; ++tau) { const TwRefs<E> tw = {tab.data(), lds_tab.data(), pre[tau].t}; fwd_phase<E, Cfg, Pol, p>(x[tau].x, tau, tw, ar); }
+    if constexpr (p + 1 < Cfg::PHASES) {
+      for (u32 tau = 0; tau < T; ++tau) ex_store<E, Cfg, p, p>(x[tau].x, tau, lds.data());
+      for (u32 tau = 0; tau < T; ++tau) ex_load<E, Cfg, p, p + 1>(x[tau].x, tau, lds.data());
+    }
+  });
+  for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r)
+    lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[tau].x[r], ar) : x[tau].x[r];
+  for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) out[Cfg::jidx(0, tau, r)] = lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
+  return 0;
+}
+
+template <typename E, bool LAZY>
+int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
+  switch (t.logn) {
+    case 8: return fused_ntt_emu<E, 8, 2, LAZY>(t, mode, in, out);
+    case 9: return fused_ntt_emu<E, 9, 3, LAZY>(t, mode, in, out);
+    case 10: return fused_ntt_emu<E, 10, 4, LAZY>(t, mode, in, out);
+    case 11: return fused_ntt_emu<E, 11, 3, LAZY>(t, mode, in, out);
+    case 12: return fused_ntt_emu<E, 12, 3, LAZY>(t, mode, in, out);
+    default: return 7;
+  }
+}
+
 template <typename E, bool LAZY>
 int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch) {
   switch (t.logn) {
@@ -169,6 +231,14 @@ int emu_fused_poly_mult(uint32_t n, uint64_t q, uint64_t psi, int force_canonica
   const HostTables t = h_build_tables(n, q, psi, !force_canonical);
   if (t.elem_bytes == 8) return t.lazy ? fused_dispatch<u64, true>(t, a, b, c, batch) : fused_dispatch<u64, false>(t, a, b, c, batch);
   return t.lazy ? fused_dispatch<u32, true>(t, a, b, c, batch) : fused_dispatch<u32, false>(t, a, b, c, batch);
+}
+
+// mode: 0 twist + forward (natural out), 1 cg_ntt, 2 cg_intt — the register-tiled standalone transforms
+int emu_fused_ntt(uint32_t n, uint64_t q, uint64_t psi, int force_canonical, int mode, const uint64_t* in, uint64_t* out) {
+  if (!params_ok(n, q, psi)) return 2;
+  const HostTables t = h_build_tables(n, q, psi, !force_canonical);
+  if (t.elem_bytes == 8) return t.lazy ? fused_ntt_dispatch<u64, true>(t, mode, in, out) : fused_ntt_dispatch<u64, false>(t, mode, in, out);
+  return t.lazy ? fused_ntt_dispatch<u32, true>(t, mode, in, out) : fused_ntt_dispatch<u32, false>(t, mode, in, out);
 }
 
 int emu_is_lazy(uint32_t n, uint64_t q, uint64_t psi) {

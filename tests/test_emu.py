@@ -132,3 +132,28 @@ def test_fused_emulation_other_sizes(emu, oracle, n, q):
     ref = oracle.poly_mult(a, b, q, psi)
     for canonical in (False, True):
         assert np.array_equal(emu.fused(n, q, psi, a, b, canonical=canonical), ref)
+
+
+@pytest.mark.parametrize("tag", ["P256", "P1024", "P4096", "P4096_60"])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_fused_standalone_transforms_emulation_matches_golden(emu, golden, tag, canonical):
+    g = golden(tag)
+    for name in g.cases("ntt"):
+        x, X = g[name + "_x"], g[name + "_X"]
+        assert np.array_equal(emu.fused_ntt(g.n, g.q, g.psi, 1, x, canonical), X), name                        # cg_ntt
+        assert np.array_equal(emu.fused_ntt(g.n, g.q, g.psi, 2, X, canonical), x % np.uint64(g.q)), name       # cg_intt
+    assert np.array_equal(emu.fused_ntt(g.n, g.q, g.psi, 0, g["lcg12_mul_a"], canonical), g["lcg1_fwd"])        # forward_ntt_bench
+
+
+@pytest.mark.parametrize("n", [512, 2048])
+def test_fused_standalone_transforms_other_sizes(emu, oracle, n):
+    from tiny_ntt_amd import numtheory
+    for q in (8380417, 1152921504606830593):
+        psi = numtheory.find_psi(n, q)
+        omega = psi * psi % q
+        rng = np.random.default_rng(n)
+        word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1
+        x = rng.integers(0, word, n, dtype=np.uint64, endpoint=True)        # any word value is taken mod q
+        X = oracle.cg_ntt(x, omega, q)
+        assert np.array_equal(emu.fused_ntt(n, q, psi, 1, x), X)
+        assert np.array_equal(emu.fused_ntt(n, q, psi, 2, X), x % np.uint64(q))

@@ -63,6 +63,9 @@ def test_transforms_and_stage_traces_match_reference_golden(eng, golden, tag):
     w = min(16, g.n)
     for name in g.cases("ntt"):
         x, X = g[name + "_x"], g[name + "_X"]
+        for v in ("auto", "fused") if plan.has_fused else ():
+            assert np.array_equal(plan.ntt_forward(x.astype(plan.dtype), variant=v).astype(np.uint64), X), f"{name} {v}"
+            assert np.array_equal(plan.ntt_inverse(X.astype(plan.dtype), variant=v).astype(np.uint64), x % np.uint64(g.q)), f"{name} {v} inverse"
         for v in ("cg", "cg8", "cg8_padded"):
             assert np.array_equal(plan.ntt_forward(x.astype(plan.dtype), variant=v).astype(np.uint64), X), f"{name} {v}"
             assert np.array_equal(plan.ntt_inverse(X.astype(plan.dtype), variant=v).astype(np.uint64), x % np.uint64(g.q)), f"{name} {v} inverse"
@@ -70,8 +73,9 @@ def test_transforms_and_stage_traces_match_reference_golden(eng, golden, tag):
             assert np.array_equal(out.astype(np.uint64), X)
             assert np.array_equal(trace[:, :w].astype(np.uint64), g[name + "_trace16"]), f"{name} {v} per-stage trace (cg_ntt.py:60-62)"
     if tag != "P4":
-        fwd = plan.twisted_ntt_forward(g["lcg12_mul_a"].astype(plan.dtype))
-        assert np.array_equal(fwd.astype(np.uint64), g["lcg1_fwd"])
+        for v in ("auto", "cg", "cg8"):
+            fwd = plan.twisted_ntt_forward(g["lcg12_mul_a"].astype(plan.dtype), variant=v)
+            assert np.array_equal(fwd.astype(np.uint64), g["lcg1_fwd"]), v
 
 
 # ---------------------------------------------------------------- seeded random vs the oracle
@@ -91,10 +95,11 @@ def test_random_batches_vs_oracle_incl_unreduced_inputs(eng, oracle, tag):
     for v in variants_of(plan):
         got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
         assert np.array_equal(got, ref), f"{tag} {v}: {np.count_nonzero(got != ref)} coefficients differ"
-    A = plan.ntt_forward(a.astype(plan.dtype)).astype(np.uint64)
-    for r in (0, 1, 5):
-        assert np.array_equal(A[r], oracle.cg_ntt(a[r], plan.omega, q))
-    assert np.array_equal(plan.ntt_inverse(A.astype(plan.dtype)).astype(np.uint64), a % np.uint64(q))
+    for v in (["fused"] if plan.has_fused else []) + ["cg"]:
+        A = plan.ntt_forward(a.astype(plan.dtype), variant=v).astype(np.uint64)
+        for r in (0, 1, 2, 5):
+            assert np.array_equal(A[r], oracle.cg_ntt(a[r], plan.omega, q)), (tag, v, r)
+        assert np.array_equal(plan.ntt_inverse(A.astype(plan.dtype), variant=v).astype(np.uint64), a % np.uint64(q)), (tag, v)
 
 
 def test_ragged_and_empty_batches(eng, oracle):
@@ -305,8 +310,10 @@ def test_device_buffers_streams_and_aliasing(eng):
         plan.poly_mult(a, b, out=a)
     with pytest.raises(eng.TinyNttError):
         plan.poly_mult(a.cpu(), b.cpu())
-    with pytest.raises(eng.TinyNttError, match="only the CG variants"):
-        plan.ntt_forward(a, variant="fused")
+    with pytest.raises(eng.TinyNttError, match="per-stage traces need a CG variant"):
+        plan.ntt_forward_trace(plan.to_host(a[:1]), variant="fused")
+    assert torch.equal(plan.ntt_forward(a, variant="fused"), plan.ntt_forward(a, variant="cg"))
+    assert torch.equal(plan.ntt_inverse(plan.ntt_forward(a)), a)
     assert plan.kernel_name("fused") == "polymul_fused_kernel" and plan.kernel_name("cg8") == "cg_kernel"
 
 

@@ -108,6 +108,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, q, elem_bytes, &p->d_omega_inv_pow);
   if (e == hipSuccess) e = upload_tw(t.psi_pow, q, elem_bytes, &p->d_psi_pow);
   if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, q, elem_bytes, &p->d_psi_inv_ninv);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, q, elem_bytes, &p->d_psi_inv_pow);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -119,7 +120,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
 extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   if (!p) return TN_OK;
   (void)hipSetDevice(p->device);
-  void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_scratch};
+  void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_psi_inv_pow, p->d_scratch};
   for (void* t : tabs) if (t) (void)hipFree(t);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -206,8 +207,8 @@ extern "C" tn_status tn_schoolbook_dev(tn_plan* p, const void* a, const void* b,
 
 extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out) {
   if (!p || !host_out) return fail(TN_EINVAL, "tn_plan_export_table: NULL argument");
-  const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv};
-  if (which < 0 || which > 5) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
+  const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv, p->d_psi_inv_pow};
+  if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
   TN_HIP(hipSetDevice(p->device));
   // device records are {w, w'} pairs; only the constants w are exported, as uint64
@@ -224,9 +225,17 @@ static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st) return st;
   TN_HIP(hipSetDevice(p->device));
-  if (variant == TN_VARIANT_AUTO) variant = TN_VARIANT_CG;
+  if (variant == TN_VARIANT_AUTO) variant = (p->has_fused && !trace) ? TN_VARIANT_FUSED : TN_VARIANT_CG;
+  if (variant == TN_VARIANT_FUSED) {
+    // register-tiled kernel: same results, no per-stage trace (its internal stages are not the CG stages)
+    if (!p->has_fused) return fail(TN_EUNSUPPORTED, std::string(fn) + ": fused kernel not built for this n; use TN_VARIANT_CG");
+    if (trace) return fail(TN_EUNSUPPORTED, std::string(fn) + ": per-stage traces need a CG variant");
+    const int fmode = mode == CG_NTT_FWD ? FNTT_CYCLIC_FWD : (mode == CG_NTT_INV ? FNTT_CYCLIC_INV : FNTT_TWIST_FWD);
+    TN_HIP(launch_ntt_fused(p, fmode, in, out, batch, pick_stream(p, stream)));
+    return TN_OK;
+  }
   CgSel sel;
-  if (!cg_sel(variant, &sel)) return fail(TN_EUNSUPPORTED, std::string(fn) + ": only the CG variants implement the untwisted transforms");
+  if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, std::string(fn) + ": unknown variant");
   TN_HIP(launch_cg(p, mode, sel.group, sel.padded, in, nullptr, out, trace, batch, pick_stream(p, stream)));
   return TN_OK;
 }

@@ -148,6 +148,10 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
     return o;
   }
   static constexpr int NPRE = (tw_src(PHASES - 1) == TW_REGS) ? pre_off(LOGN) : 1;
+  // LDS image in NATURAL coefficient order, used by the standalone transforms to move between HBM order and the
+  // last phase's bit-reversed register layout.  Consecutive lanes of that phase hit indices that differ in their
+  // HIGH bits (bit-reversed thread id), so bits [5,9) are XORed into the low bits to spread them over the banks.
+  TN_HD static u32 nat_addr(u32 k) { return k ^ ((k >> 5) & 15u); }
   // the part of the twiddle index that comes from the thread id; a compile-time 0 where every
   // thread of the workgroup shares the twiddles (phase 0), so those loads become scalar loads
   // ... and wave-uniform (made a scalar) where it only depends on the wave index (pos(p) >= 6).

@@ -231,6 +231,112 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
 }
 
+// Standalone transforms on the register-tiled machinery, natural order in and out:
+//   FNTT_TWIST_FWD   X[k] = sum_i x[i] psi^(i(2k+1))   = twist + cg_ntt = forward_ntt_bench (benchmark_ntt_60bit.cpp:161-165)
+//   FNTT_CYCLIC_FWD  cg_ntt(x, omega=psi^2)            (cg_ntt.py:29-65)  = the above on x[i] psi^-i
+//   FNTT_CYCLIC_INV  cg_intt(X, omega=psi^2)           (cg_ntt.py:68-75)  = merged inverse, then * psi^i
+// The merged transform produces / consumes bit-reversed order in the last phase's register layout;
+// one extra LDS transpose through a natural-order image turns that into unit-stride HBM accesses.
+template <typename E, int LOGN, int LPT, bool LAZY, int MODE>
+__global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))
+ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab, const typename TwOf<E>::type* __restrict__ twist,
+                 const E* __restrict__ in, E* __restrict__ out, u32 batch) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  typedef Policy<E, LAZY> Pol;
+  typedef typename TwOf<E>::type Tw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  E* lds = reinterpret_cast<E*>(tn_smem);
+  const u32 tau = threadIdx.x;
+  Tw* lds_tab = reinterpret_cast<Tw*>(lds + Cfg::lds_elems());
+  for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) lds_tab[i] = tab[Cfg::lds_tw_lo() + i];
+  __syncthreads();
+  constexpr int LAST = Cfg::PHASES - 1;
+  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
+    const size_t off = (size_t)row << LOGN;
+    E x[Cfg::R];
+    if (MODE == FNTT_CYCLIC_INV) {
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) x[r] = Pol::load(in[off + Cfg::jidx(0, tau, r)], ar);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))] = x[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))];
+      Tw pre[Cfg::NPRE];
+      tw_prefetch<E, Cfg>(pre, tau, tab);
+      const TwRefs<E> tw = {tab, lds_tab, pre};
+      inverse_all<E, Cfg, Pol>(x, tau, tw, ar, lds, []() {});
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) {
+        const u32 j = Cfg::jidx(0, tau, r);
+        out[off + j] = mul_tw(x[r], twist[j], ar.q);             // * psi^j
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) {
+        const u32 j = Cfg::jidx(0, tau, r);
+        const E v = in[off + j];
+        x[r] = (MODE == FNTT_CYCLIC_FWD) ? Pol::load(mul_tw_lazy(v, twist[j], ar.q), ar) : Pol::load(v, ar);   // * psi^-j
+      }
+      forward_all<E, Cfg, Pol>(x, tau, tab, lds_tab, ar, lds);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r)
+        lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[r], ar) : x[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) out[off + Cfg::jidx(0, tau, r)] = lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename E, int LOGN, int LPT, bool LAZY>
+static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
+  typedef FusedCfg<E, LOGN, LPT> Cfg;
+  typedef typename TwOf<E>::type Tw;
+  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw);
+  const PlanView<E> pv = make_view<E>(p);
+  const void* kern = nullptr;
+  const Tw *tab = nullptr, *twist = nullptr;
+  if (mode == FNTT_TWIST_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_TWIST_FWD>; tab = pv.psi_brv; twist = pv.psi_pow; }
+  else if (mode == FNTT_CYCLIC_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_FWD>; tab = pv.psi_brv; twist = pv.psi_inv_pow; }
+  else { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_INV>; tab = pv.psi_inv_brv; twist = pv.psi_pow; }
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  int per_cu = 0;
+  hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
+  if (qe != hipSuccess || per_cu < 1) per_cu = 1;
+  const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
+  const u32 grid = (u32)(batch < resident ? batch : resident);
+  Arith<E> ar = pv.ar;
+  const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
+  void* args[] = {&ar, &tab, &twist, &in_, &out_, &b32};
+  return hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
+}
+
+template <typename E, bool LAZY>
+static hipError_t launch_nttf_e(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
+  switch (p->logn) {
+    case 8: return launch_nttf_t<E, 8, 2, LAZY>(p, mode, in, out, batch, s);
+    case 9: return launch_nttf_t<E, 9, 3, LAZY>(p, mode, in, out, batch, s);
+    case 10: return launch_nttf_t<E, 10, 4, LAZY>(p, mode, in, out, batch, s);
+    case 11: return launch_nttf_t<E, 11, 3, LAZY>(p, mode, in, out, batch, s);
+    case 12: return launch_nttf_t<E, 12, TN_FUSED_LPT12, LAZY>(p, mode, in, out, batch, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
+  if (batch == 0) return hipSuccess;
+  if (p->elem_bytes == 8)
+    return p->lazy ? launch_nttf_e<u64, true>(p, mode, in, out, batch, s) : launch_nttf_e<u64, false>(p, mode, in, out, batch, s);
+  return p->lazy ? launch_nttf_e<u32, true>(p, mode, in, out, batch, s) : launch_nttf_e<u32, false>(p, mode, in, out, batch, s);
+}
+
 // log2(n) -> coefficients per thread (log2)
 static int fused_lpt(u32 logn) {
   switch (logn) {

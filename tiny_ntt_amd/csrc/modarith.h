@@ -86,6 +86,17 @@ TN_HD u32 wave_uniform(u32 x) {
 #endif
 }
 
+// reverse the low `bits` bits of v (bit_reverse, new_reference/cg_ntt.py:13-18)
+TN_HD u32 bitrev(u32 v, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(v) >> (32 - bits);
+#else
+  u32 r = 0;
+  for (int i = 0; i < bits; ++i) { r = (r << 1) | (v & 1u); v >>= 1; }
+  return r;
+#endif
+}
+
 TN_HD u32 mulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 
 // In {T-2, T-1, T} for T = floor(a*wp / 2^64): the high partial product plus the high

@@ -25,6 +25,7 @@ struct tn_plan {
   void* d_omega_pow = nullptr;     // [n/2] omega^j   (cg_ntt.py:51,54 — pow(omega_s, i//k) = omega^(k*(i//k)))
   void* d_omega_inv_pow = nullptr; // [n/2] omega^-j
   void* d_psi_pow = nullptr;       // [n]   psi^i     (twist, cg_ntt.py:82-83)
+  void* d_psi_inv_pow = nullptr;   // [n]   psi^-i  (pre-twist of the fused cyclic forward transform)
   void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
   void* d_scratch = nullptr;       // host-entry staging (grown on demand)
   size_t scratch_bytes = 0;
@@ -32,6 +33,7 @@ struct tn_plan {
 
 namespace tn {
 
+enum FusedNttMode { FNTT_TWIST_FWD = 0, FNTT_CYCLIC_FWD = 1, FNTT_CYCLIC_INV = 2 };
 enum CgMode { CG_NTT_FWD = 0, CG_NTT_INV = 1, CG_POLYMUL = 2, CG_TWIST_FWD = 3, CG_CYCLIC_POLYMUL = 4 };
 
 template <typename E> struct PlanView {
@@ -44,6 +46,7 @@ template <typename E> struct PlanView {
   const Tw* omega_inv_pow;
   const Tw* psi_pow;
   const Tw* psi_inv_ninv;
+  const Tw* psi_inv_pow;
 };
 
 template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
@@ -57,6 +60,7 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
   v.psi_brv = (const Tw*)p->d_psi_brv; v.psi_inv_brv = (const Tw*)p->d_psi_inv_brv;
   v.omega_pow = (const Tw*)p->d_omega_pow; v.omega_inv_pow = (const Tw*)p->d_omega_inv_pow;
   v.psi_pow = (const Tw*)p->d_psi_pow; v.psi_inv_ninv = (const Tw*)p->d_psi_inv_ninv;
+  v.psi_inv_pow = (const Tw*)p->d_psi_inv_pow;
   return v;
 }
 
@@ -65,6 +69,7 @@ bool fused_supported(u32 logn, int elem_bytes);
 const char* fused_kernel_name(const tn_plan* p);
 const char* cg_kernel_name(const tn_plan* p, int group, bool padded);
 hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
+hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s);
 hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
                      void* trace, size_t batch, hipStream_t s);
 hipError_t launch_pointwise(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);

@@ -13,7 +13,7 @@ struct HostTables {
   bool lazy = false;
   u32 fold_c = 0;
   u64 n_inv = 0, ninv_w1 = 0;
-  std::vector<u64> psi_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
+  std::vector<u64> psi_pow, psi_inv_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
 };
 
 inline u32 h_brv(u32 v, u32 bits) {
@@ -50,7 +50,8 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72
   t.n_inv = h_powmod(n % q, q - 2, q);                          // :74
-  std::vector<u64> psi_inv_pow(n);
+  std::vector<u64>& psi_inv_pow = t.psi_inv_pow;
+  psi_inv_pow.resize(n);
   t.psi_pow.resize(n); t.psi_inv_ninv.resize(n); t.psi_brv.resize(n); t.psi_inv_brv.resize(n);
   t.omega_pow.resize(n / 2); t.omega_inv_pow.resize(n / 2);
   u64 f = 1, g = 1;

@@ -252,7 +252,7 @@ class Plan:
         """O(n^2) direct negacyclic product on device (benchmark_ntt_60bit.cpp:167-180): independent checker."""
         return self._binary_dev(self._lib.tn_schoolbook_dev, a, b, out, stream)
 
-    TABLES = {"psi_pow": 0, "psi_inv_ninv": 1, "omega_pow": 2, "omega_inv_pow": 3, "psi_brv": 4, "psi_inv_brv": 5}
+    TABLES = {"psi_pow": 0, "psi_inv_ninv": 1, "omega_pow": 2, "omega_inv_pow": 3, "psi_brv": 4, "psi_inv_brv": 5, "psi_inv_pow": 6}
 
     def export_table(self, which) -> np.ndarray:
         """One of the plan's device tables as uint64 values (see tn_plan_export_table)."""
@@ -275,15 +275,16 @@ class Plan:
         _check(self._lib, fn_host(self._h, hx.ctypes.data, hy.ctypes.data, hx.shape[0], v))
         return hy[0] if squeeze else hy
 
-    def ntt_forward(self, x, variant="cg", out=None, stream=None):
-        """cg_ntt(x, omega=psi^2) (cg_ntt.py:29-65): untwisted, natural order in and out."""
+    def ntt_forward(self, x, variant="auto", out=None, stream=None):
+        """cg_ntt(x, omega=psi^2) (cg_ntt.py:29-65): untwisted, natural order in and out.
+        variant "auto"/"fused": register-tiled kernel; "cg"/"cg8"/"cg8_padded": the reference's stage sweep."""
         return self._ntt(self._lib.tn_ntt_forward_dev, self._lib.tn_ntt_forward_host, x, variant, out, stream)
 
-    def ntt_inverse(self, x, variant="cg", out=None, stream=None):
+    def ntt_inverse(self, x, variant="auto", out=None, stream=None):
         """cg_intt(x, omega=psi^2) (cg_ntt.py:68-75)."""
         return self._ntt(self._lib.tn_ntt_inverse_dev, self._lib.tn_ntt_inverse_host, x, variant, out, stream)
 
-    def twisted_ntt_forward(self, x, variant="cg", out=None, stream=None):
+    def twisted_ntt_forward(self, x, variant="auto", out=None, stream=None):
         """twist + forward: forward_ntt_bench (benchmark_ntt_60bit.cpp:161-165).  Device tensors only."""
         if not _is_torch(x):
             import torch

@@ -16,3 +16,19 @@ for name, n, q, psi, B, w in CFG:
     ms = min(plan.time_poly_mult(a, b, c, 10) for _ in range(3))
     print(f"{name:62s} {ms:8.3f} ms  {B/ms*1e3/1e6:8.2f} M polymul/s  {B*3*n*w/ms/1e6:7.0f} GB/s  frac {B*3*n*w/ms/1e6/8000:.3f}  lazy={plan.is_lazy}", flush=True)
     del a, b, c; plan.close(); torch.cuda.empty_cache()
+
+# standalone transforms (NTTs/s) at the benchmark shape
+n, q, psi = 4096, 1152921504606830593, 431606828070683274
+plan = engine.Plan(n, q, psi)
+B = 65536
+x = plan.fill_lcg(B, 1, 2); y = torch.empty_like(x)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for name, fn in (("cg_ntt fused", lambda: plan.ntt_forward(x, variant="fused", out=y)), ("cg_intt fused", lambda: plan.ntt_inverse(x, variant="fused", out=y)),
+                 ("twist+ntt fused", lambda: plan.twisted_ntt_forward(x, variant="fused", out=y)), ("cg_ntt cg", lambda: plan.ntt_forward(x[:8192], variant="cg", out=y[:8192]))):
+    fn(); torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(5): fn()
+    ev1.record(); torch.cuda.synchronize()
+    rows = 8192 if name.endswith(" cg") else B
+    ms = ev0.elapsed_time(ev1) / 5
+    print(f"{name:18s} {ms:8.3f} ms  {rows/ms*1e3/1e6:8.2f} M NTT/s  {rows*2*n*8/ms/1e6:7.0f} GB/s (2nw bytes)", flush=True)
