@@ -21,6 +21,19 @@ static tn_status fail_hip(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return TN_EHIP;
 }
+// Every entry point runs on the plan's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) { err = hipSetDevice(dev); changed = (err == hipSuccess); }
+  }
+  ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+#define TN_ON_DEVICE(p) DeviceGuard tn_guard_((p)->device); if (tn_guard_.err != hipSuccess) return fail_hip(tn_guard_.err, "hipSetDevice")
+
 #define TN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_, #call); } while (0)
 
 extern "C" const char* tn_last_error(void) { return g_err.c_str(); }
@@ -84,7 +97,8 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   if (he != hipSuccess || ndev <= 0)
     return fail(TN_ENODEVICE, "no HIP device visible; libtinyntt has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(TN_EINVAL, "device index out of range");
-  TN_HIP(hipSetDevice(device));
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
 
   tn_plan* p = new (std::nothrow) tn_plan();
   if (!p) return fail(TN_ENOMEM, "plan allocation failed");
@@ -119,7 +133,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
 
 extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   if (!p) return TN_OK;
-  (void)hipSetDevice(p->device);
+  DeviceGuard guard(p->device);
   void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_psi_inv_pow, p->d_scratch};
   for (void* t : tabs) if (t) (void)hipFree(t);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -162,7 +176,7 @@ extern "C" tn_status tn_poly_mult_dev(tn_plan* p, const void* a, const void* b, 
                                       void* stream) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_dev");
   if (st) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   hipStream_t s = pick_stream(p, stream);
   if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
   if (variant == TN_VARIANT_FUSED) {
@@ -180,7 +194,7 @@ extern "C" tn_status tn_cyclic_poly_mult_dev(tn_plan* p, const void* a, const vo
                                              void* stream) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_cyclic_poly_mult_dev");
   if (st) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   if (variant == TN_VARIANT_AUTO) variant = TN_VARIANT_CG;
   CgSel sel;
   if (!cg_sel(variant, &sel)) return fail(TN_EUNSUPPORTED, "tn_cyclic_poly_mult_dev: only the CG variants implement the untwisted product");
@@ -192,7 +206,7 @@ extern "C" tn_status tn_pointwise_mul_dev(tn_plan* p, const void* a, const void*
   if (!p) return fail(TN_EINVAL, "tn_pointwise_mul_dev: plan is NULL");
   if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_pointwise_mul_dev: batch too large");
   if (batch && (!a || !b || !c)) return fail(TN_EINVAL, "tn_pointwise_mul_dev: NULL buffer");
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(launch_pointwise(p, a, b, c, batch, pick_stream(p, stream)));
   return TN_OK;
 }
@@ -200,7 +214,7 @@ extern "C" tn_status tn_pointwise_mul_dev(tn_plan* p, const void* a, const void*
 extern "C" tn_status tn_schoolbook_dev(tn_plan* p, const void* a, const void* b, void* c, size_t batch, void* stream) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_schoolbook_dev");
   if (st) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(launch_schoolbook(p, a, b, c, batch, pick_stream(p, stream)));
   return TN_OK;
 }
@@ -210,7 +224,7 @@ extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out)
   const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv, p->d_psi_inv_pow};
   if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   // device records are {w, w'} pairs; only the constants w are exported, as uint64
   std::vector<unsigned char> raw(count * 2 * (size_t)p->elem_bytes);
   TN_HIP(hipMemcpy(raw.data(), tabs[which], raw.size(), hipMemcpyDeviceToHost));
@@ -224,7 +238,7 @@ static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t
                          void* trace, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   if (variant == TN_VARIANT_AUTO) variant = (p->has_fused && !trace) ? TN_VARIANT_FUSED : TN_VARIANT_CG;
   if (variant == TN_VARIANT_FUSED) {
     // register-tiled kernel: same results, no per-stage trace (its internal stages are not the CG stages)
@@ -263,7 +277,7 @@ static tn_status ensure_scratch(tn_plan* p, size_t bytes) {
 extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_host");
   if (st || batch == 0) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
   if ((st = ensure_scratch(p, 3 * bytes))) return st;
   char* d = (char*)p->d_scratch;
@@ -278,7 +292,7 @@ extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b,
 static tn_status ntt_host(tn_plan* p, int mode, const void* in, void* out, void* trace, size_t batch, tn_variant v, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st || batch == 0) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
   const size_t tbytes = trace ? bytes * p->logn : 0;
   if ((st = ensure_scratch(p, 2 * bytes + tbytes))) return st;
@@ -305,7 +319,7 @@ extern "C" tn_status tn_ntt_forward_trace_host(tn_plan* p, const void* in, void*
 extern "C" tn_status tn_fill_lcg_dev(tn_plan* p, void* dst, size_t batch, uint64_t seed0, uint64_t seed_stride, void* stream) {
   if (!p || (batch && !dst)) return fail(TN_EINVAL, "tn_fill_lcg_dev: NULL argument");
   if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_fill_lcg_dev: batch too large");
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(launch_fill_lcg(p, dst, batch, seed0, seed_stride, pick_stream(p, stream)));
   return TN_OK;
 }
@@ -313,14 +327,14 @@ extern "C" tn_status tn_fill_lcg_dev(tn_plan* p, void* dst, size_t batch, uint64
 extern "C" tn_status tn_checksum_rows_dev(tn_plan* p, const void* src, uint64_t* out, size_t batch, void* stream) {
   if (!p || (batch && (!src || !out))) return fail(TN_EINVAL, "tn_checksum_rows_dev: NULL argument");
   if (batch > 0xffffffffull) return fail(TN_EINVAL, "tn_checksum_rows_dev: batch too large");
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(launch_checksum(p, src, out, batch, pick_stream(p, stream)));
   return TN_OK;
 }
 
 extern "C" tn_status tn_plan_synchronize(tn_plan* p) {
   if (!p) return fail(TN_EINVAL, "tn_plan_synchronize: plan is NULL");
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(hipStreamSynchronize(p->stream));
   return TN_OK;
 }
@@ -330,7 +344,7 @@ extern "C" tn_status tn_time_poly_mult_dev(tn_plan* p, const void* a, const void
   if (!ms_per_launch || iters < 1) return fail(TN_EINVAL, "tn_time_poly_mult_dev: bad iters/ms pointer");
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_time_poly_mult_dev");
   if (st) return st;
-  TN_HIP(hipSetDevice(p->device));
+  TN_ON_DEVICE(p);
   TN_HIP(hipEventRecord(p->ev0, p->stream));
   for (int i = 0; i < iters; ++i)
     if ((st = tn_poly_mult_dev(p, a, b, c, batch, variant, nullptr))) return st;
