@@ -133,7 +133,7 @@ int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
   switch (t.logn) {
     case 8: return fused_ntt_emu<E, 8, 2, LAZY>(t, mode, in, out);
     case 9: return fused_ntt_emu<E, 9, 3, LAZY>(t, mode, in, out);
-    case 10: return fused_ntt_emu<E, 10, 4, LAZY>(t, mode, in, out);
+    case 10: return fused_ntt_emu<E, 10, 3, LAZY>(t, mode, in, out);
     case 11: return fused_ntt_emu<E, 11, 3, LAZY>(t, mode, in, out);
     case 12: return fused_ntt_emu<E, 12, 3, LAZY>(t, mode, in, out);
     default: return 7;
@@ -145,7 +145,7 @@ int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size
   switch (t.logn) {
     case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch);
     case 9: return fused_polymul_emu<E, 9, 3, LAZY>(t, a, b, c, batch);
-    case 10: return fused_polymul_emu<E, 10, 4, LAZY>(t, a, b, c, batch);
+    case 10: return fused_polymul_emu<E, 10, 3, LAZY>(t, a, b, c, batch);
     case 11: return fused_polymul_emu<E, 11, 3, LAZY>(t, a, b, c, batch);
     case 12: return fused_polymul_emu<E, 12, 3, LAZY>(t, a, b, c, batch);
     default: return 7;
@@ -258,13 +258,13 @@ long emu_cfg_probe(int logn, int elem_bytes, int what, unsigned a0, unsigned a1,
   if (elem_bytes == 8) {
     if (logn == 8) return cfg_probe<u64, 8, 2>(what, a0, a1, a2);
     if (logn == 9) return cfg_probe<u64, 9, 3>(what, a0, a1, a2);
-    if (logn == 10) return cfg_probe<u64, 10, 4>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u64, 10, 3>(what, a0, a1, a2);
     if (logn == 11) return cfg_probe<u64, 11, 3>(what, a0, a1, a2);
     if (logn == 12) return cfg_probe<u64, 12, 3>(what, a0, a1, a2);
   } else {
     if (logn == 8) return cfg_probe<u32, 8, 2>(what, a0, a1, a2);
     if (logn == 9) return cfg_probe<u32, 9, 3>(what, a0, a1, a2);
-    if (logn == 10) return cfg_probe<u32, 10, 4>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u32, 10, 3>(what, a0, a1, a2);
     if (logn == 11) return cfg_probe<u32, 11, 3>(what, a0, a1, a2);
     if (logn == 12) return cfg_probe<u32, 12, 3>(what, a0, a1, a2);
   }

@@ -33,6 +33,9 @@
 #ifndef TN_FUSED_PAIR
 #define TN_FUSED_PAIR 0          // 1: transform a and b phase by phase together (shared twiddle loads, more live registers)
 #endif
+#ifndef TN_FUSED_LPT10
+#define TN_FUSED_LPT10 3         // log2(coefficients per thread) for n = 1024 (8 per thread: 219 vs 188 M products/s at 24 bits)
+#endif
 #ifndef TN_FUSED_LPT12
 #define TN_FUSED_LPT12 3         // log2(coefficients per thread) for n = 4096
 #endif
@@ -323,7 +326,7 @@ static hipError_t launch_nttf_e(const tn_plan* p, int mode, const void* in, void
   switch (p->logn) {
     case 8: return launch_nttf_t<E, 8, 2, LAZY>(p, mode, in, out, batch, s);
     case 9: return launch_nttf_t<E, 9, 3, LAZY>(p, mode, in, out, batch, s);
-    case 10: return launch_nttf_t<E, 10, 4, LAZY>(p, mode, in, out, batch, s);
+    case 10: return launch_nttf_t<E, 10, TN_FUSED_LPT10, LAZY>(p, mode, in, out, batch, s);
     case 11: return launch_nttf_t<E, 11, 3, LAZY>(p, mode, in, out, batch, s);
     case 12: return launch_nttf_t<E, 12, TN_FUSED_LPT12, LAZY>(p, mode, in, out, batch, s);
     default: return hipErrorInvalidValue;
@@ -342,7 +345,7 @@ static int fused_lpt(u32 logn) {
   switch (logn) {
     case 8: return 2;
     case 9: return 3;
-    case 10: return 4;
+    case 10: return TN_FUSED_LPT10;
     case 11: return 3;
     case 12: return TN_FUSED_LPT12;
     default: return 0;
@@ -378,7 +381,7 @@ static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b,
   switch (p->logn) {
     case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s);
     case 9: return launch_fused_t<E, 9, 3, LAZY>(p, a, b, c, batch, s);
-    case 10: return launch_fused_t<E, 10, 4, LAZY>(p, a, b, c, batch, s);
+    case 10: return launch_fused_t<E, 10, TN_FUSED_LPT10, LAZY>(p, a, b, c, batch, s);
     case 11: return launch_fused_t<E, 11, 3, LAZY>(p, a, b, c, batch, s);
     case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s);
     default: return hipErrorInvalidValue;
