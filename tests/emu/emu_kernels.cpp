@@ -64,10 +64,14 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
   for (size_t row = 0; row < batch; ++row) {
     const size_t off = row << LOGN;
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau)
+    {
       for (int r = 0; r < Cfg::R; ++r) {
-        xa[tau].x[r] = Pol::load((E)a[off + Cfg::jidx(0, tau, r)], ar);
-        xb[tau].x[r] = Pol::load((E)b[off + Cfg::jidx(0, tau, r)], ar);
+        xa[tau].x[r] = (E)a[off + Cfg::jidx(0, tau, r)];
+        xb[tau].x[r] = (E)b[off + Cfg::jidx(0, tau, r)];
       }
+      load_reduce<E, Cfg, Pol>(xa[tau].x, ar);
+      load_reduce<E, Cfg, Pol>(xb[tau].x, ar);
+    }
     forward(xa);
     forward(xb);
     for (u32 tau = 0; tau < (u32)Cfg::THREADS; ++tau) pointwise<E, Cfg, Pol>(xa[tau].x, xb[tau].x, ar);

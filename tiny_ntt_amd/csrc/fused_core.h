@@ -311,8 +311,10 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
       sched_fence();
     }
     if (S::fwd_fold(s)) {
+      // only the "u" side of this stage's butterflies needs its bound back: the "v" side goes through the
+      // twiddle multiply, which accepts any word; both outputs then inherit u's bound + TMUL
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) x[r] = fold(x[r], ar.k, ar.fold_c);
+      for (int r = 0; r < Cfg::R; ++r) if (!(r & (1 << bpos))) x[r] = fold(x[r], ar.k, ar.fold_c);
     }
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) {
@@ -368,6 +370,14 @@ TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
       if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
     }
   });
+}
+
+// Reduction of freshly loaded operand words before the first forward stage: only the registers that enter
+// stage 0 as "u" (top register bit clear) must be bounded / canonical; the others are multiplied first.
+template <typename E, typename Cfg, typename Pol>
+TN_HD void load_reduce(E (&x)[Cfg::R], const Arith<E>& ar) {
+#pragma unroll
+  for (int r = 0; r < Cfg::R / 2; ++r) x[r] = Pol::load(x[r], ar);
 }
 
 // LDS transposes.  e = exchange index (between phase e and e+1); `from` = phase

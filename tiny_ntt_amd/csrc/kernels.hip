@@ -187,7 +187,8 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
     E xn[Cfg::R];
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xn[r] = Pol::load(xb[r], ar);
+    for (int r = 0; r < Cfg::R; ++r) xn[r] = xb[r];
+    load_reduce<E, Cfg, Pol>(xn, ar);
     sched_fence();
 #if TN_STORE_AT_TOP
     st_result<E, Cfg>(c, prev, tau, xa);
@@ -205,8 +206,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
     for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
 #endif
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xb[r] = Pol::load(xb[r], ar);
+    load_reduce<E, Cfg, Pol>(xb, ar);
     forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds);
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
