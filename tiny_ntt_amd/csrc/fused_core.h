@@ -32,6 +32,12 @@
 #define TN_PREFETCH_LAST 2       // last-phase (thread-private) twiddles: 0 = loaded at use; 1 = one stage early (28 VGPRs live
                                  // through a butterfly stage: spills at 128); 2 = just before the transpose that precedes the phase
 #endif
+#ifndef TN_TW_AHEAD
+#define TN_TW_AHEAD 0            // scalar (wave-uniform) twiddles: 1 = requested one butterfly stage before their use, so the
+                                 // scalar-cache / L2 latency hides behind a stage of arithmetic; 0 = loaded at use.
+                                 // Measured on MI355X (n=4096, 60-bit): 1 is 2% SLOWER (3.28 vs 3.21 ms) - the kernel runs
+                                 // at the package power cap, where hidden stalls buy nothing and the fences cost ILP.
+#endif
 #ifndef TN_ABL_UNIFORM_TW
 #define TN_ABL_UNIFORM_TW 0      // 1: every thread uses the phase-0 (wave-uniform) twiddle indices -> no vector twiddle loads
 #endif
@@ -275,6 +281,19 @@ TN_HD typename TwOf<E>::type tw_get(const TwRefs<E>& t, u32 thi, int g) {
   return t.glob[idx];
 }
 
+// Phases whose twiddles are wave-uniform (scalar loads): they are requested one stage ahead (TN_TW_AHEAD).
+template <typename Cfg, int PH> constexpr bool tw_ahead() {
+  return TN_TW_AHEAD && (Cfg::tw_src(PH) == Cfg::TW_UNIFORM || Cfg::tw_src(PH) == Cfg::TW_WAVE);
+}
+// All twiddles one thread uses in stage S_ of phase PH: R >> (bpos + 1) of them.
+template <typename E, typename Cfg, int PH, int S_>
+TN_HD void tw_stage(const TwRefs<E>& t, u32 tau, typename TwOf<E>::type (&w)[Cfg::R / 2]) {
+  constexpr int bpos = (Cfg::LOGN - 1 - S_) - Cfg::pos(PH);
+  const u32 thi = Cfg::thi(PH, tau);
+#pragma unroll
+  for (int g = 0; g < (Cfg::R >> (bpos + 1)); ++g) w[g] = tw_get<E, Cfg, PH, S_>(t, thi, g);
+}
+
 // Fetch the calling thread's last-phase twiddles into registers (issued ahead of their use).
 template <typename E, typename Cfg>
 TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
@@ -297,8 +316,11 @@ TN_HD void tw_prefetch(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const 
 // ---------------------------------------------------------------------------
 // One forward phase on a thread's registers.
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, typename TwOf<E>::type (&cur)[Cfg::R / 2]) {
+  // cur[]: with tw_ahead<PH>, the first stage's twiddles, already requested by the caller (before the transpose
+  // that precedes this phase); each stage then requests the next stage's before its own butterflies.
   typedef Sched<Pol, Cfg::LOGN> S;
+  typedef typename TwOf<E>::type Tw;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
@@ -310,6 +332,10 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
       tw_prefetch_raw<E, Cfg>(tw.pre, tau, tw.glob);
       sched_fence();
     }
+    // scalar loads return out of order, so a wait for cur[] also waits for everything requested after it:
+    // the next stage's twiddles are therefore requested right AFTER this stage's first butterfly has consumed cur[]
+    Tw nxt[Cfg::R / 2];
+    constexpr bool AHEAD = tw_ahead<Cfg, PH>() && s + 1 < Cfg::stage_end(PH);
     if (S::fwd_fold(s)) {
       // only the "u" side of this stage's butterflies needs its bound back: the "v" side goes through the
       // twiddle multiply, which accepts any word; both outputs then inherit u's bound + TMUL
@@ -319,10 +345,26 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) {
       if (r & (1 << bpos)) continue;
-      Pol::ct(x[r], x[r | (1 << bpos)], tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1)), ar);
+      const Tw w = tw_ahead<Cfg, PH>() ? cur[r >> (bpos + 1)] : tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
+      Pol::ct(x[r], x[r | (1 << bpos)], w, ar);
+      if constexpr (AHEAD) if (r == 0) {
+        sched_fence();
+        tw_stage<E, Cfg, PH, (AHEAD ? s + 1 : s)>(tw, tau, nxt);
+        sched_fence();
+      }
       if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
     }
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int g = 0; g < Cfg::R / 2; ++g) cur[g] = nxt[g];
+    }
   });
+}
+template <typename E, typename Cfg, typename Pol, int PH>
+TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+  typename TwOf<E>::type cur[Cfg::R / 2];
+  if constexpr (tw_ahead<Cfg, PH>()) tw_stage<E, Cfg, PH, Cfg::stage_begin(PH)>(tw, tau, cur);
+  fwd_phase<E, Cfg, Pol, PH>(x, tau, tw, ar, cur);
 }
 
 // The same forward phase on TWO polynomials at once (a and b of one product): every twiddle
@@ -348,15 +390,18 @@ TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const TwRefs<
   });
 }
 
-// One inverse phase (stages of phase PH in reverse order).
+// One inverse phase (stages of phase PH in reverse order).  cur[]: as in fwd_phase (first executed stage = stage_end - 1).
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, typename TwOf<E>::type (&cur)[Cfg::R / 2]) {
   typedef Sched<Pol, Cfg::LOGN> S;
+  typedef typename TwOf<E>::type Tw;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<0, Cfg::stage_end(PH) - Cfg::stage_begin(PH)>([&](auto i_) {
     constexpr int s = Cfg::stage_end(PH) - 1 - decltype(i_)::value;   // forward stage number being undone
     constexpr int g = Cfg::LOGN - 1 - s;                               // execution order of the inverse
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    Tw nxt[Cfg::R / 2];
+    constexpr bool AHEAD = tw_ahead<Cfg, PH>() && s - 1 >= Cfg::stage_begin(PH) && s - 1 >= 1;   // stage 0 uses ar.ninv*
     if (S::inv_fold(g)) {
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) x[r] = fold(x[r], ar.k, ar.fold_c);
@@ -366,10 +411,28 @@ TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
     for (int r = 0; r < Cfg::R; ++r) {
       if (r & (1 << bpos)) continue;
       if (s == 0) Pol::template gs_last<BND>(x[r], x[r | (1 << bpos)], ar);
-      else Pol::template gs<BND>(x[r], x[r | (1 << bpos)], tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1)), ar);
+      else {
+        const Tw w = tw_ahead<Cfg, PH>() ? cur[r >> (bpos + 1)] : tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
+        Pol::template gs<BND>(x[r], x[r | (1 << bpos)], w, ar);
+      }
+      if constexpr (AHEAD) if (r == 0) {
+        sched_fence();
+        tw_stage<E, Cfg, PH, (AHEAD ? s - 1 : s)>(tw, tau, nxt);
+        sched_fence();
+      }
       if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
     }
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int g2 = 0; g2 < Cfg::R / 2; ++g2) cur[g2] = nxt[g2];
+    }
   });
+}
+template <typename E, typename Cfg, typename Pol, int PH>
+TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+  typename TwOf<E>::type cur[Cfg::R / 2];
+  if constexpr (tw_ahead<Cfg, PH>() && Cfg::stage_end(PH) - 1 >= 1) tw_stage<E, Cfg, PH, Cfg::stage_end(PH) - 1>(tw, tau, cur);
+  inv_phase<E, Cfg, Pol, PH>(x, tau, tw, ar, cur);
 }
 
 // Reduction of freshly loaded operand words before the first forward stage: only the registers that enter

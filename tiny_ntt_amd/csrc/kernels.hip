@@ -18,6 +18,9 @@
 #ifndef TN_ABL_NO_BARRIER
 #define TN_ABL_NO_BARRIER 0      // timing ablation: cross-wave transposes without workgroup barriers (wrong results)
 #endif
+#ifndef TN_ABL_ROWMASK
+#define TN_ABL_ROWMASK 0         // timing ablation: rows & mask -> operands and results stay in L2 (no HBM traffic; wrong results)
+#endif
 #ifndef TN_ABL_NO_GLOBAL
 #define TN_ABL_NO_GLOBAL 0       // timing ablation: operands synthesised in registers instead of loaded from HBM
 #endif
@@ -81,18 +84,31 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
 // stage early (into pre[], inside fwd_phase), so their latency hides behind that stage and the transpose.
 template <typename E, typename Cfg, typename Pol>
 __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
-                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds) {
+                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
+                                            const typename TwOf<E>::type* first = nullptr) {
+  // first: stage 0's only twiddle (table entry 1), if the caller keeps it resident in registers
   typename TwOf<E>::type pre[Cfg::NPRE];
   const TwRefs<E> tw = {glob, lds_tw, pre};
+  typename TwOf<E>::type cur[Cfg::R / 2];            // scalar twiddles of the stage about to run (see TN_TW_AHEAD)
+  if constexpr (tw_ahead<Cfg, 0>()) {
+    if (first) cur[0] = *first;
+    else tw_stage<E, Cfg, 0, Cfg::stage_begin(0)>(tw, tau, cur);
+  }
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
-    fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
     if constexpr (TN_PREFETCH_LAST == 2 && p == Cfg::PHASES - 2) {
       sched_fence();                   // request the last phase's private twiddles; they fly during the transpose
       tw_prefetch<E, Cfg>(pre, tau, glob);
       sched_fence();
     }
-    if constexpr (p + 1 < Cfg::PHASES) exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
+    if constexpr (p + 1 < Cfg::PHASES) {
+      if constexpr (tw_ahead<Cfg, (p + 1 < Cfg::PHASES ? p + 1 : p)>()) {     // next phase's first scalar twiddles fly during the transpose
+        tw_stage<E, Cfg, p + 1, Cfg::stage_begin(p + 1)>(tw, tau, cur);
+        sched_fence();
+      }
+      exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
+    }
   });
 }
 
@@ -103,11 +119,20 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
 template <typename E, typename Cfg, typename Pol, typename F>
 __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds,
                                             F&& after_first) {
+  typename TwOf<E>::type cur[Cfg::R / 2];
+  if constexpr (tw_ahead<Cfg, Cfg::PHASES - 1>() && Cfg::LOGN - 1 >= 1) tw_stage<E, Cfg, Cfg::PHASES - 1, Cfg::LOGN - 1>(tw, tau, cur);
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
-    inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
+    inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
     if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
-    if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
+    if constexpr (p > 0) {
+      constexpr int pn = p > 0 ? p - 1 : 0;
+      if constexpr (tw_ahead<Cfg, pn>() && Cfg::stage_end(pn) - 1 >= 1) {
+        tw_stage<E, Cfg, pn, Cfg::stage_end(pn) - 1>(tw, tau, cur);
+        sched_fence();
+      }
+      exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
+    }
   });
 }
 
@@ -118,6 +143,9 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 #if TN_ABL_NO_GLOBAL
   return (E)(tau * 2654435761u + 7 * r + row);
 #else
+#if TN_ABL_ROWMASK
+  row &= TN_ABL_ROWMASK;
+#endif
 #if TN_NT_STREAM
   return __builtin_nontemporal_load(p + (((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)));   // streamed once: keep L2 for the twiddle tables
 #else
@@ -128,6 +156,9 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 
 template <typename E, typename Cfg>
 __device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, const E (&x)[Cfg::R]) {
+#if TN_ABL_ROWMASK
+  row &= TN_ABL_ROWMASK;
+#endif
   const size_t off = (size_t)row << Cfg::LOGN;
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) {
@@ -166,6 +197,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // product) while the inverse transform of the current row runs; b itself is requested at the
   // top of the row and not needed until a's forward transform is done.
   E xa[Cfg::R], xb[Cfg::R];
+  const Tw w_stage0 = tab_fwd[1];          // forward stage 0 uses this one twiddle in every row: resident in SGPRs
   u32 row = blockIdx.x;
   if (row < batch) {
 #pragma unroll
@@ -198,7 +230,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     sched_fence();
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
-    forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds);
+    forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
 #if TN_PARK_LDS
     // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
     // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
@@ -207,7 +239,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
 #endif
     load_reduce<E, Cfg, Pol>(xb, ar);
-    forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds);
+    forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
     tw_prefetch<E, Cfg>(pre, tau, tab_inv);

@@ -67,6 +67,12 @@ TN_HD u64 opaque64(u64 x) {
 #endif
   return x;
 }
+TN_HD u32 opaque32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+  return x;
+}
 
 // Scheduling fence (device only): the machine scheduler may not move instructions across it.
 // Used between groups of butterflies to bound how many are in flight (live registers).
@@ -126,7 +132,9 @@ TN_HD u64 mul_tw_acc(u64 u, u64 a, Tw64 t, u64 q) {
   hi = (u64)h0 * n1 + hi;
   hi = (u64)h1 * n0 + hi;
   hi = opaque64(hi);
-  const u32 rh = (u32)(lo >> 32) + (u32)hi;                     // one 32-bit add on the high dword
+  // one 32-bit add on the high dword; opaque, or LLVM rewrites it as lo + (hi << 32): two moves
+  // and a 64-bit add (8 issue cycles instead of 2)
+  const u32 rh = opaque32((u32)(lo >> 32) + (u32)hi);
   return ((u64)rh << 32) | (u32)lo;
 }
 
