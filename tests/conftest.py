@@ -168,6 +168,8 @@ class Emu:
         L.emu_barrett64.argtypes = [u64, u64, u64]; L.emu_barrett64.restype = u64
         L.emu_barrett32.argtypes = [u32, u32, u32]; L.emu_barrett32.restype = u32
         L.emu_fold64.argtypes = [u64, u64]; L.emu_fold64.restype = u64
+        L.emu_pw_fast_ok.argtypes = [u64]; L.emu_pw_fast_ok.restype = ctypes.c_int
+        L.emu_pointwise_lazy64.argtypes = [u64, u64, u64]; L.emu_pointwise_lazy64.restype = u64
         L.emu_fold32.argtypes = [u32, u32]; L.emu_fold32.restype = u32
 
     def fused(self, n, q, psi, a, b, canonical=False):

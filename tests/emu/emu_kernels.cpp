@@ -288,6 +288,13 @@ uint32_t emu_barrett32(uint32_t a, uint32_t b, uint32_t q) {
   return mulmod_barrett(a, b, q, (u64)((((unsigned __int128)1) << (2 * k)) / q), k);
 }
 uint64_t emu_fold64(uint64_t x, uint64_t q) { const int k = h_bitlen(q); return fold(x, k, (u32)((((u64)1) << k) - q)); }
+// lazy 64-bit pointwise product on two ARBITRARY words (folds them first, as pointwise() does); -1 if (k, c) is not admissible
+int emu_pw_fast_ok(uint64_t q) { const int k = h_bitlen(q); return h_pw_fast_ok(q, k, (((u64)1) << k) - q) ? 1 : 0; }
+uint64_t emu_pointwise_lazy64(uint64_t a, uint64_t b, uint64_t q) {
+  const int k = h_bitlen(q);
+  Arith<u64> ar; ar.q = q; ar.k = k; ar.fold_c = (u32)((((u64)1) << k) - q); ar.mu = 0;
+  return pointwise_lazy(a, b, ar);
+}
 uint32_t emu_fold32(uint32_t x, uint32_t q) { const int k = h_bitlen(q); return fold(x, k, (u32)((((u64)1) << k) - q)); }
 
 }  // extern "C"

@@ -100,6 +100,24 @@ def test_mul_tw32_and_barrett32(emu):
                 assert emu.lib.emu_barrett32(a, b, q) == a * b % q
 
 
+def test_pointwise_lazy64_any_words(emu):
+    """Split-and-fold product of the lazy 64-bit policy (mulmod_solinas_lazy): exact mod q and < 2q for ANY two
+    words, for every admissible q = 2^k - c; inadmissible (k, c) are reported by h_pw_fast_ok."""
+    rnd = random.Random(33)
+    qs = [PARAMS["P4096_60"][1], 2 ** 59 - 2 ** 15 + 1, 2 ** 50 - 2 ** 13 + 1 - 0, 2 ** 40 - 87, 2 ** 33 - 9, 2 ** 60 - 93, 2 ** 60 - (2 ** 28 - 57)]
+    for q in qs:
+        assert emu.lib.emu_pw_fast_ok(q) == 1, q
+        top = min(2 ** 64, 16 * q)
+        vals = EDGE64 + [q - 1, q, q + 1, 2 * q, 15 * q, top - 1, 2 ** (q.bit_length()) - 1, 2 ** (q.bit_length())]
+        vals = [v % 2 ** 64 for v in vals] + [rnd.randrange(2 ** 64) for _ in range(300)]
+        for a in vals[:40]:
+            for b in vals:
+                r = emu.lib.emu_pointwise_lazy64(a, b, q)
+                assert r < 2 * q and r % q == a * b % q, (q, a, b)
+    for q in (2 ** 60 - 2 ** 30 + 1, 2 ** 36 - 2 ** 17 - 1, 2 ** 61 - 1):        # c too large for the bounds / k > 60
+        assert emu.lib.emu_pw_fast_ok(q) == 0, q
+
+
 def test_barrett64_boundaries(emu):
     rnd = random.Random(3)
     for q in (PARAMS["P4096_60"][1], 4611686018326724609, 2 ** 61 - 1, 1099511627689):

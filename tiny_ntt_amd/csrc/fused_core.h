@@ -177,8 +177,9 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
 // small and LIMIT*q <= 2^W; checked at plan creation (plan.cpp).
 // Canonical: every value in [0,q) after every operation; any odd q < 2^62 / 2^31.
 template <typename E> struct LazyTraits;
-template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4; };   // mul_tw_lazy < 4q
-template <> struct LazyTraits<u32> { static constexpr int LIMIT = 64, TMUL = 2; };   // mul_tw_lazy < 2q
+// PW = bound of the lazy pointwise product (pointwise() below)
+template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4, PW = 2; };   // mul_tw_lazy < 4q
+template <> struct LazyTraits<u32> { static constexpr int LIMIT = 64, TMUL = 2, PW = 4; };   // mul_tw_lazy < 2q
 
 // Lazy Cooley-Tukey butterfly: u' = u + t, v' = u - t + TMUL*q with t = v*w mod q + {0..TMUL-1}q.
 // 64-bit lanes: the add of u rides on the mad chain for free, and v' = 2u + 4q - u'
@@ -197,7 +198,7 @@ TN_HD void ct_lazy(u32& u, u32& v, Tw32 w, u32 q) {
 template <typename E, bool LAZY> struct Policy {
   typedef typename TwOf<E>::type Tw;
   static constexpr bool lazy = LAZY;
-  static constexpr int LIMIT = LazyTraits<E>::LIMIT, TMUL = LazyTraits<E>::TMUL;
+  static constexpr int LIMIT = LazyTraits<E>::LIMIT, TMUL = LazyTraits<E>::TMUL, PW = LazyTraits<E>::PW;
 
   // value bound (in multiples of q) after loading an arbitrary word
   TN_HD static E load(E x, const Arith<E>& ar) {
@@ -256,7 +257,7 @@ template <typename P, int LOGN> struct Sched {
   }
   // inverse stage index g = 0 .. LOGN-1 in execution order (g = 0 is distance 1)
   static constexpr int inv_in(int g) {
-    int b = P::lazy ? 4 : 1;                     // pointwise output: lazy Barrett < 4q, else canonical
+    int b = P::lazy ? P::PW : 1;                 // pointwise output: lazy < PW q, else canonical
     for (int i = 0; i < g; ++i) { if (2 * b > P::LIMIT) b = 2; b = (2 * b > P::TMUL) ? 2 * b : P::TMUL; }
     return b;
   }
@@ -474,14 +475,21 @@ TN_HD void ex_load(E (&x)[Cfg::R], u32 tau, const E* lds) {
 }
 
 // Pointwise product in the last phase's register layout.  Canonical policy: canonical result.
-// Lazy policy: operands are folded below 2^k + eps and the Barrett product is left in [0, 4q)
-// (Sched::inv_in starts from that bound), which saves four conditional subtractions per product.
+// Lazy policy: operands are folded below 2^k + eps and the product is left below LazyTraits::PW q
+// (Sched::inv_in starts from that bound).  64-bit lanes: split-and-fold product; a plan is only lazy
+// if its (k, c) passes h_pw_fast_ok().
+TN_HD u64 pointwise_lazy(u64 a, u64 b, const Arith<u64>& ar) {
+  return mulmod_solinas_lazy(fold(a, ar.k, ar.fold_c), fold(b, ar.k, ar.fold_c), ar.k, ar.fold_c);       // < 2q
+}
+TN_HD u32 pointwise_lazy(u32 a, u32 b, const Arith<u32>& ar) {
+  return mulmod_barrett_lazy(fold(a, ar.k, ar.fold_c), fold(b, ar.k, ar.fold_c), ar.q, ar.mu, ar.k);   // < 4q
+}
 template <typename E, typename Cfg, typename Pol>
 TN_HD void pointwise(E (&xa)[Cfg::R], const E (&xb)[Cfg::R], const Arith<E>& ar) {
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) {
     if (Pol::lazy)
-      xa[r] = mulmod_barrett_lazy(fold(xa[r], ar.k, ar.fold_c), fold(xb[r], ar.k, ar.fold_c), ar.q, ar.mu, ar.k);
+      xa[r] = pointwise_lazy(xa[r], xb[r], ar);
     else
       xa[r] = mulmod_barrett(xa[r], xb[r], ar.q, ar.mu, ar.k);
     if (r & 1) sched_fence();          // two products in flight at a time: bounds the live temporaries

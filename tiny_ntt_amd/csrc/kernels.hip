@@ -46,6 +46,11 @@
 #define TN_FUSED_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (4 -> <= 128 VGPRs)
 #endif
 
+#ifdef TN_MARKS
+#define TN_MARK(n) asm volatile("; TNMARK " n)
+#else
+#define TN_MARK(n)
+#endif
 namespace tn {
 
 // ============================================================================
@@ -96,7 +101,9 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
   }
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
+    TN_MARK("fwd_phase");
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
+    TN_MARK("fwd_other");
     if constexpr (TN_PREFETCH_LAST == 2 && p == Cfg::PHASES - 2) {
       sched_fence();                   // request the last phase's private twiddles; they fly during the transpose
       tw_prefetch<E, Cfg>(pre, tau, glob);
@@ -123,7 +130,9 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
   if constexpr (tw_ahead<Cfg, Cfg::PHASES - 1>() && Cfg::LOGN - 1 >= 1) tw_stage<E, Cfg, Cfg::PHASES - 1, Cfg::LOGN - 1>(tw, tau, cur);
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
+    TN_MARK("inv_phase");
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
+    TN_MARK("inv_other");
     if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
     if constexpr (p > 0) {
       constexpr int pn = p > 0 ? p - 1 : 0;
@@ -217,6 +226,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   for (; row < batch; row += gridDim.x) {
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
+    TN_MARK("loop_top");
     E xn[Cfg::R];
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xn[r] = xb[r];
@@ -247,7 +257,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
     for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
 #endif
+    TN_MARK("pointwise");
     pointwise<E, Cfg, Pol>(xa, xb, ar);
+    TN_MARK("after_pointwise");
     const u32 next = row + gridDim.x;
     const TwRefs<E> twi = {tab_inv, lds_inv, pre};
     inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {

@@ -161,23 +161,36 @@ TN_HD u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu, int k) {
   return csub(r, q);                                          // second subtract kept: single-subtract bound unproven
 }
 
-// Same recipe without the final subtractions, for operands slightly above 2^k (a, b < 2^k + 2^(k-20)):
-// then p/q - q1*mu/2^(k+1) < 2 + 2^-18, so q2 is at most 3 below floor(p/q) and the result,
-// congruent to a*b, lies in [0, 4q).
-TN_HD u64 mulmod_barrett_lazy(u64 a, u64 b, u64 q, u64 mu, int k) {
-  u64 plo = a * b, phi = mulhi64(a, b);
-  u64 q1 = (phi << (64 - (k - 1))) | (plo >> (k - 1));
-  u64 mlo = q1 * mu, mhi = mulhi64(q1, mu);
-  u64 q2 = (mhi << (64 - (k + 1))) | (mlo >> (k + 1));
-  return plo - q2 * q;
-}
-
 // One Barrett step with quotient estimate x >> k, for q = 2^k - c (k >= 32):  result == x (mod q),
 // < 2^k + (x >> k) * c.  Written on the high dword so it is 2 two-cycle ops + one v_mad_u64_u32.
 TN_HD u64 fold(u64 x, int k, u32 c) {
   const u32 top = (u32)(x >> 32) >> (k - 32);
   const u64 lowmask = (((u64)1) << k) - 1;
   return (x & lowmask) + (u64)top * c;
+}
+
+// Two-operand product for q = 2^k - c with SMALL c (2^k == c mod q), used by the pointwise step of the lazy policy:
+// the 128-bit product is split at bit k and the high part folded back twice.  9 multiplies instead of the
+// 18 of the Barrett recipe above.  a, b: outputs of fold() (< 2^k + 2^(64-k) c).  Result == a*b (mod q), < 2q.
+// Every intermediate bound is verified for the plan's (k, c) on the host: h_pw_fast_ok() in plan_tables.h.
+TN_HD u64 mulmod_solinas_lazy(u64 a, u64 b, int k, u32 c) {
+  const int s = k - 32;                                          // 0 <= s <= 28
+  const u32 ms = (1u << s) - 1u;
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 m0 = (u64)a0 * b0;
+  const u64 m1 = (u64)a0 * b1 + (m0 >> 32);
+  const u64 m2 = (u64)a1 * b0 + (u32)m1;
+  const u64 m3 = (u64)a1 * b1 + (m1 >> 32) + (m2 >> 32);         // P = m3 2^64 + lo32(m2) 2^32 + lo32(m0)
+  const u32 p0 = (u32)m0, p1 = (u32)m2;
+  const u32 ph0 = (u32)((((u64)(u32)m3 << 32) | p1) >> s);       // Ph = P >> k  (two dwords)
+  const u32 ph1 = (u32)(m3 >> s);
+  const u64 pl = ((u64)(p1 & ms) << 32) | p0;                    // Pl = P mod 2^k
+  const u64 t = (u64)ph0 * c + pl;                               // P == Pl + Ph c = t + (ph1 c) 2^32
+  const u64 u = (u64)ph1 * c;
+  const u32 uh = (u32)(u >> s);                                  // (u 2^32) >> k
+  const u32 vh = (u32)(t >> 32) + ((u32)u & ms);                 // high dword of V = t + ((u 2^32) mod 2^k); low dword = t's
+  const u32 top = (vh >> s) + uh;                                // (V >> k) + ((u 2^32) >> k)
+  return (((u64)(vh & ms) << 32) | (u32)t) + (u64)top * c;
 }
 
 // ---- 32-bit lanes -----------------------------------------------------------

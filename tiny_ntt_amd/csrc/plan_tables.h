@@ -36,6 +36,33 @@ inline bool h_lazy_ok(u64 q, int elem_bytes, u32* fold_c) {
   return fits && fold_ok;
 }
 
+// Is mulmod_solinas_lazy (the lazy 64-bit pointwise product) valid for this (k, c)?  Worst-case value of every intermediate of
+// that routine for this (k, c), with operands at the fold() output bound; all must fit their words and the
+// result must stay below 2q.
+inline bool h_pw_fast_ok(u64 q, int k, u64 c) {
+  typedef unsigned __int128 u128;
+  if (k < 32 || k > 60 || c == 0 || c >= ((u64)1 << 31)) return false;
+  const int s = k - 32;
+  const u128 one = 1, w64 = one << 64, w32 = one << 32;
+  const u128 amax = (one << k) - 1 + ((one << (64 - k)) - 1) * c;          // fold() output bound
+  if (amax >= (one << 62)) return false;
+  const u128 pmax = amax * amax;
+  const u128 phmax = pmax >> k;
+  if (phmax >= w64) return false;
+  const u128 ph1max = phmax >> 32;
+  const u128 umax = ph1max * c;
+  if (umax >= w64) return false;
+  const u128 uhmax = umax >> s;
+  const u128 tmax = (one << k) - 1 + (w32 - 1) * c;
+  if (tmax >= w64) return false;
+  const u128 vhmax = (tmax >> 32) + ((one << s) - 1);
+  if (vhmax >= w32) return false;
+  const u128 topmax = (vhmax >> s) + uhmax;
+  if (topmax >= w32) return false;
+  const u128 rmax = (one << k) - 1 + topmax * c;
+  return rmax < (u128)2 * q;
+}
+
 // Preconditions (checked by the caller): n = 2^logn >= 4, q odd prime < 2^62, psi^n == -1.
 inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   HostTables t;
@@ -46,6 +73,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   t.k = h_bitlen(q);
   t.mu = (u64)((((unsigned __int128)1) << (2 * t.k)) / q);
   t.lazy = h_lazy_ok(q, t.elem_bytes, &t.fold_c) && allow_lazy;
+  if (t.lazy && t.elem_bytes == 8 && !h_pw_fast_ok(q, t.k, t.fold_c)) t.lazy = false;     // 64-bit lazy pointwise product needs it
   if (!t.lazy) t.fold_c = 0;
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72

@@ -5,7 +5,7 @@ import collections, re, sys
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l and l.rstrip().endswith(("function", ":")) or (l.startswith("_ZN") and key in l and ":" in l))
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 ins = collections.Counter()
 for l in lines[start:end + 1]:
     m = re.match(r"^\s+((?:v|s|ds|global|buffer|flat|scratch)_[a-z0-9_]+)", l)
