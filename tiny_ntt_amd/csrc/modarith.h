@@ -171,7 +171,7 @@ TN_HD u64 fold(u64 x, int k, u32 c) {
 
 // Two-operand product for q = 2^k - c with SMALL c (2^k == c mod q), used by the pointwise step of the lazy policy:
 // the 128-bit product is split at bit k and the high part folded back twice.  9 multiplies instead of the
-// 18 of the Barrett recipe above.  a, b: outputs of fold() (< 2^k + 2^(64-k) c).  Result == a*b (mod q), < 2q.
+// 18 of a two-operand Barrett.  a: output of fold() (< 2^k + 2^(64-k) c); b: any value < 14q.  Result == a*b (mod q), < 2q.
 // Every intermediate bound is verified for the plan's (k, c) on the host: h_pw_fast_ok() in plan_tables.h.
 TN_HD u64 mulmod_solinas_lazy(u64 a, u64 b, int k, u32 c) {
   const int s = k - 32;                                          // 0 <= s <= 28

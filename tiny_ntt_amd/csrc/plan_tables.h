@@ -37,7 +37,7 @@ inline bool h_lazy_ok(u64 q, int elem_bytes, u32* fold_c) {
 }
 
 // Is mulmod_solinas_lazy (the lazy 64-bit pointwise product) valid for this (k, c)?  Worst-case value of every intermediate of
-// that routine for this (k, c), with operands at the fold() output bound; all must fit their words and the
+// that routine for this (k, c), with one operand at the fold() output bound and the other at (LIMIT-2) q; all must fit their words and the
 // result must stay below 2q.
 inline bool h_pw_fast_ok(u64 q, int k, u64 c) {
   typedef unsigned __int128 u128;
@@ -46,7 +46,9 @@ inline bool h_pw_fast_ok(u64 q, int k, u64 c) {
   const u128 one = 1, w64 = one << 64, w32 = one << 32;
   const u128 amax = (one << k) - 1 + ((one << (64 - k)) - 1) * c;          // fold() output bound
   if (amax >= (one << 62)) return false;
-  const u128 pmax = amax * amax;
+  const u128 bmax = (u128)(LazyTraits<u64>::LIMIT - 2) * q;                // the unfolded operand (Sched::fwd_out)
+  if (bmax >= w64) return false;
+  const u128 pmax = amax * bmax;
   const u128 phmax = pmax >> k;
   if (phmax >= w64) return false;
   const u128 ph1max = phmax >> 32;
