@@ -100,6 +100,15 @@ tn_status tn_poly_mult_host(tn_plan *plan, const void *a, const void *b, void *c
                             tn_variant variant);
 
 /*
+ * The *_host entry points cut the batch into chunks that flow H2D -> kernel -> D2H on three
+ * streams through a fixed set of device staging slots (copies overlap the kernels when the host
+ * buffers are pinned; device staging stays bounded whatever the batch).  rows = rows per chunk,
+ * 0 = automatic (32 MiB per operand).  No counterpart in the reference (its callers hand over
+ * Python lists / std::vector, cg_ntt.py:78, benchmark_ntt_60bit.cpp:148).
+ */
+tn_status tn_plan_set_host_chunk_rows(tn_plan *plan, size_t rows);
+
+/*
  * Untwisted cyclic transforms with omega = psi^2, natural order in and out.
  * tn_ntt_forward_*  replaces cg_ntt(a_prime, omega_n, modulus)  (cg_ntt.py:29-65),
  *                   cg_ntt_8butterfly (cg_ntt_8butterfly.py:41-97) with TN_VARIANT_CG8.

@@ -117,6 +117,31 @@ def test_ragged_and_empty_batches(eng, oracle):
         plan.poly_mult(a[:, :100], b[:, :100])
 
 
+def test_host_entry_points_pipeline_chunks(eng, oracle):
+    """*_host entry points: the H2D -> kernel -> D2H pipeline with more chunks than staging slots, a ragged last
+    chunk, pageable and pinned host buffers; results identical to the single-chunk path and to the oracle."""
+    import torch
+    n, q, psi = PARAMS["P4096_60"]
+    plan = eng.Plan(n, q, psi)                       # private plan: the chunk size is per-plan state
+    rng = np.random.default_rng(77)
+    B = 23
+    a = rng.integers(0, q, (B, n), dtype=np.uint64); b = rng.integers(0, q, (B, n), dtype=np.uint64)
+    ref = oracle.poly_mult(a, b, q, psi)
+    whole = plan.poly_mult(a, b)
+    assert np.array_equal(whole, ref)
+    pa, pb = torch.from_numpy(a).pin_memory().numpy(), torch.from_numpy(b).pin_memory().numpy()
+    for rows in (1, 2, 5, 7, 23, 64):                # 23, 12, 5, 4, 1, 1 chunks
+        plan.set_host_chunk_rows(rows)
+        assert np.array_equal(plan.poly_mult(a, b), ref), rows
+        assert np.array_equal(plan.poly_mult(pa, pb), ref), rows
+        A = plan.ntt_forward(a, variant="fused")
+        assert np.array_equal(A[B - 1], oracle.cg_ntt(a[B - 1], plan.omega, q)), rows
+        assert np.array_equal(plan.ntt_inverse(A, variant="fused"), a), rows
+    plan.set_host_chunk_rows(0)
+    assert np.array_equal(plan.poly_mult(a, b, variant="cg"), ref)
+    plan.close()
+
+
 def test_generic_moduli_run_canonical(eng, oracle):
     n = 256
     for q in (754974721, 2305843009196916737, 7681 * 0 + 12289):

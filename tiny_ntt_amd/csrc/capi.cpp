@@ -138,6 +138,13 @@ extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   for (void* t : tabs) if (t) (void)hipFree(t);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
+  for (int i = 0; i < tn_plan::HOST_SLOTS; ++i) {
+    if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]);
+    if (p->ev_k[i]) (void)hipEventDestroy(p->ev_k[i]);
+    if (p->ev_out[i]) (void)hipEventDestroy(p->ev_out[i]);
+  }
+  if (p->copy_in) (void)hipStreamDestroy(p->copy_in);
+  if (p->copy_out) (void)hipStreamDestroy(p->copy_out);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return TN_OK;
@@ -274,33 +281,105 @@ static tn_status ensure_scratch(tn_plan* p, size_t bytes) {
   return TN_OK;
 }
 
+// Host-buffer pipeline.  The batch is cut into chunks of `rows` rows; chunk i uses staging slot i % HOST_SLOTS
+// (n_in input buffers + 1 output buffer on the device) and flows through three streams:
+//   copy_in : H2D of the chunk's inputs      (waits until the kernel that last read the slot has finished)
+//   stream  : the kernel                     (waits for the H2D and for the D2H that last read the slot's output)
+//   copy_out: D2H of the chunk's output      (waits for the kernel)
+// so with pinned host memory PCIe traffic in both directions overlaps the kernels.  With pageable memory the
+// runtime's copies block the calling thread; the issue order below (inputs of chunk i+1 before the output of
+// chunk i) still overlaps the next H2D with the current kernel.  Device staging is bounded by
+// HOST_SLOTS * (n_in + 1) * chunk bytes whatever the batch.
+static const size_t HOST_CHUNK_BYTES = (size_t)32 << 20;
+
+static tn_status host_pipe_init(tn_plan* p) {
+  if (p->copy_in) return TN_OK;
+  TN_HIP(hipStreamCreateWithFlags(&p->copy_in, hipStreamNonBlocking));
+  TN_HIP(hipStreamCreateWithFlags(&p->copy_out, hipStreamNonBlocking));
+  for (int i = 0; i < tn_plan::HOST_SLOTS; ++i) {
+    TN_HIP(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
+    TN_HIP(hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming));
+    TN_HIP(hipEventCreateWithFlags(&p->ev_out[i], hipEventDisableTiming));
+  }
+  return TN_OK;
+}
+
+// launch(in0, in1, out, rows): enqueue the kernel for one chunk on p->stream (device pointers)
+template <typename Launch>
+static tn_status host_pipeline(tn_plan* p, int n_in, const void* const* in, void* out, size_t batch, Launch&& launch) {
+  tn_status st;
+  if ((st = host_pipe_init(p))) return st;
+  const size_t row_bytes = (size_t)p->n * (size_t)p->elem_bytes;
+  size_t rows = p->host_chunk_rows ? p->host_chunk_rows : (HOST_CHUNK_BYTES / row_bytes ? HOST_CHUNK_BYTES / row_bytes : 1);
+  if (rows > batch) rows = batch;
+  const size_t nchunks = (batch + rows - 1) / rows;
+  const int slots = nchunks < (size_t)tn_plan::HOST_SLOTS ? (int)nchunks : tn_plan::HOST_SLOTS;
+  const size_t chunk_bytes = rows * row_bytes;
+  if ((st = ensure_scratch(p, (size_t)slots * (size_t)(n_in + 1) * chunk_bytes))) return st;
+  char* base = (char*)p->d_scratch;
+  auto slot_buf = [&](int slot, int j) { return base + ((size_t)slot * (size_t)(n_in + 1) + (size_t)j) * chunk_bytes; };
+  auto rows_of = [&](size_t i) { return i + 1 < nchunks ? rows : batch - i * rows; };
+  auto issue_in = [&](size_t i) -> tn_status {
+    const int slot = (int)(i % (size_t)slots);
+    const size_t off = i * chunk_bytes, bytes = rows_of(i) * row_bytes;
+    if (i >= (size_t)slots) TN_HIP(hipStreamWaitEvent(p->copy_in, p->ev_k[slot], 0));
+    for (int j = 0; j < n_in; ++j)
+      TN_HIP(hipMemcpyAsync(slot_buf(slot, j), (const char*)in[j] + off, bytes, hipMemcpyHostToDevice, p->copy_in));
+    TN_HIP(hipEventRecord(p->ev_in[slot], p->copy_in));
+    return TN_OK;
+  };
+  if ((st = issue_in(0))) return st;
+  for (size_t i = 0; i < nchunks; ++i) {
+    const int slot = (int)(i % (size_t)slots);
+    TN_HIP(hipStreamWaitEvent(p->stream, p->ev_in[slot], 0));
+    if (i >= (size_t)slots) TN_HIP(hipStreamWaitEvent(p->stream, p->ev_out[slot], 0));
+    if ((st = launch(slot_buf(slot, 0), n_in > 1 ? slot_buf(slot, 1) : nullptr, slot_buf(slot, n_in), rows_of(i)))) return st;
+    TN_HIP(hipEventRecord(p->ev_k[slot], p->stream));
+    if (i + 1 < nchunks && (st = issue_in(i + 1))) return st;
+    TN_HIP(hipStreamWaitEvent(p->copy_out, p->ev_k[slot], 0));
+    TN_HIP(hipMemcpyAsync((char*)out + i * chunk_bytes, slot_buf(slot, n_in), rows_of(i) * row_bytes, hipMemcpyDeviceToHost, p->copy_out));
+    TN_HIP(hipEventRecord(p->ev_out[slot], p->copy_out));
+  }
+  TN_HIP(hipStreamSynchronize(p->copy_out));
+  TN_HIP(hipStreamSynchronize(p->stream));
+  TN_HIP(hipStreamSynchronize(p->copy_in));
+  return TN_OK;
+}
+
+extern "C" tn_status tn_plan_set_host_chunk_rows(tn_plan* p, size_t rows) {
+  if (!p) return fail(TN_EINVAL, "tn_plan_set_host_chunk_rows: plan is NULL");
+  p->host_chunk_rows = rows;
+  return TN_OK;
+}
+
 extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_host");
   if (st || batch == 0) return st;
   TN_ON_DEVICE(p);
-  const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
-  if ((st = ensure_scratch(p, 3 * bytes))) return st;
-  char* d = (char*)p->d_scratch;
-  TN_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, p->stream));
-  TN_HIP(hipMemcpyAsync(d + bytes, b, bytes, hipMemcpyHostToDevice, p->stream));
-  if ((st = tn_poly_mult_dev(p, d, d + bytes, d + 2 * bytes, batch, variant, nullptr))) return st;
-  TN_HIP(hipMemcpyAsync(c, d + 2 * bytes, bytes, hipMemcpyDeviceToHost, p->stream));
-  TN_HIP(hipStreamSynchronize(p->stream));
-  return TN_OK;
+  const void* in[2] = {a, b};
+  return host_pipeline(p, 2, in, c, batch, [&](const void* da, const void* db, void* dc, size_t rows) {
+    return tn_poly_mult_dev(p, da, db, dc, rows, variant, nullptr);
+  });
 }
 
 static tn_status ntt_host(tn_plan* p, int mode, const void* in, void* out, void* trace, size_t batch, tn_variant v, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st || batch == 0) return st;
   TN_ON_DEVICE(p);
-  const size_t bytes = batch * p->n * (size_t)p->elem_bytes;
-  const size_t tbytes = trace ? bytes * p->logn : 0;
+  if (!trace) {
+    const void* ins[1] = {in};
+    return host_pipeline(p, 1, ins, out, batch, [&](const void* di, const void*, void* dout, size_t rows) {
+      return ntt_dev(p, mode, di, dout, rows, v, nullptr, nullptr, fn);
+    });
+  }
+  const size_t bytes = batch * p->n * (size_t)p->elem_bytes;          // traced transform: one row, one pass
+  const size_t tbytes = bytes * p->logn;
   if ((st = ensure_scratch(p, 2 * bytes + tbytes))) return st;
   char* d = (char*)p->d_scratch;
   TN_HIP(hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, p->stream));
-  if ((st = ntt_dev(p, mode, d, d + bytes, batch, v, nullptr, trace ? d + 2 * bytes : nullptr, fn))) return st;
+  if ((st = ntt_dev(p, mode, d, d + bytes, batch, v, nullptr, d + 2 * bytes, fn))) return st;
   TN_HIP(hipMemcpyAsync(out, d + bytes, bytes, hipMemcpyDeviceToHost, p->stream));
-  if (trace) TN_HIP(hipMemcpyAsync(trace, d + 2 * bytes, tbytes, hipMemcpyDeviceToHost, p->stream));
+  TN_HIP(hipMemcpyAsync(trace, d + 2 * bytes, tbytes, hipMemcpyDeviceToHost, p->stream));
   TN_HIP(hipStreamSynchronize(p->stream));
   return TN_OK;
 }

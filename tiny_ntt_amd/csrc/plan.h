@@ -19,6 +19,12 @@ struct tn_plan {
   tn::u64 one_w = 1, one_wp = 0, ninv_w = 0, ninv_wp = 0, ninv_w1_w = 0, ninv_w1_wp = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // host-buffer entry points: chunks flow H2D (copy_in) -> kernel (stream) -> D2H (copy_out) through HOST_SLOTS
+  // device staging slots; created on first use
+  static constexpr int HOST_SLOTS = 3;
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  hipEvent_t ev_in[HOST_SLOTS] = {}, ev_k[HOST_SLOTS] = {}, ev_out[HOST_SLOTS] = {};
+  size_t host_chunk_rows = 0;      // rows per chunk; 0 = automatic (HOST_CHUNK_BYTES per operand)
   // device tables (Tw32[] or Tw64[] according to elem_bytes)
   void* d_psi_brv = nullptr;       // [n]   psi^brv(i): merged forward twiddles (fused kernel)
   void* d_psi_inv_brv = nullptr;   // [n]   psi^-brv(i)

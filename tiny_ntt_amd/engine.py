@@ -33,7 +33,7 @@ PLAN_FORCE_CANONICAL = 1
 EXPORTED_SYMBOLS = (
     "tn_plan_create", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
     "tn_plan_elem_bytes", "tn_plan_device", "tn_plan_has_fused", "tn_plan_is_lazy",
-    "tn_poly_mult_dev", "tn_poly_mult_host", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
+    "tn_poly_mult_dev", "tn_poly_mult_host", "tn_plan_set_host_chunk_rows", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
     "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
     "tn_ntt_forward_host", "tn_ntt_inverse_host", "tn_ntt_forward_trace_host", "tn_twisted_ntt_forward_dev",
     "tn_fill_lcg_dev", "tn_checksum_rows_dev", "tn_plan_synchronize", "tn_time_poly_mult_dev",
@@ -77,6 +77,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         getattr(lib, name).restype = res
     lib.tn_poly_mult_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
     lib.tn_poly_mult_host.argtypes = [vp, vp, vp, vp, sz, ci]
+    lib.tn_plan_set_host_chunk_rows.argtypes = [vp, sz]
     lib.tn_cyclic_poly_mult_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
     lib.tn_pointwise_mul_dev.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.tn_schoolbook_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -202,6 +203,10 @@ class Plan:
         h = int(getattr(stream, "cuda_stream", stream))
         return ctypes.c_void_p(h if h else 1)
 
+    def set_host_chunk_rows(self, rows: int):
+        """Rows per chunk of the H2D -> kernel -> D2H pipeline behind the host-buffer entry points (0 = automatic)."""
+        _check(self._lib, self._lib.tn_plan_set_host_chunk_rows(self._h, int(rows)))
+
     # ---- the operator ----------------------------------------------------------
     def poly_mult(self, a, b, variant="auto", out=None, stream=None):
         """c[r] = a[r] * b[r] in Z_q[x]/(x^n+1).  nwc_poly_mult (cg_ntt.py:78-92), batched."""
@@ -219,7 +224,12 @@ class Plan:
         ha, hb = self._host_rows(a, "a"), self._host_rows(b, "b")
         if ha.shape != hb.shape:
             raise ValueError(f"Expected {self.n} coefficients")
-        hc = np.empty_like(ha)
+        if out is not None:                  # caller-provided (e.g. pinned) result buffer
+            if not (isinstance(out, np.ndarray) and out.dtype == self.dtype and out.flags.c_contiguous and out.size == ha.size):
+                raise ValueError("out must be a C-contiguous array of the plan's dtype with the shape of a")
+            hc = out.reshape(ha.shape)
+        else:
+            hc = np.empty_like(ha)
         _check(self._lib, self._lib.tn_poly_mult_host(self._h, ha.ctypes.data, hb.ctypes.data, hc.ctypes.data, ha.shape[0], v))
         return hc[0] if squeeze else hc
 
