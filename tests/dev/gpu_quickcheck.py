@@ -1,7 +1,7 @@
 """Ad-hoc GPU check (developer tool): every variant vs the oracle on all parameter sets + rough timings."""
 import ctypes, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tiny_ntt_amd import engine
 orc = ctypes.CDLL(os.path.join(ROOT, "oracle/_build/liboracle.so"))

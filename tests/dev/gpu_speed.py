@@ -1,7 +1,7 @@
 """Developer tool: correctness spot-check + kernel time of the fused kernel at the bench shape."""
 import os, sys, ctypes
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 from tiny_ntt_amd import engine
 n, q, psi = 4096, 1152921504606830593, 431606828070683274
