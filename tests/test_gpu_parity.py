@@ -301,8 +301,10 @@ def _full_size_properties(eng, oracle, tag, batch, check_rows):
     lhs = plan.poly_mult(s.astype(plan.dtype), plan.to_host(b[:256]))
     rhs = (plan.to_host(c[:256]).astype(np.uint64) + plan.to_host(plan.poly_mult(ap, b[:256])).astype(np.uint64)) % np.uint64(q)
     assert np.array_equal(lhs.astype(np.uint64), rhs)
-    # variants agree on a slab
-    for v in ("cg", "cg8", "cg8_padded"):
+    # EVERY row of the batch: the fused (persistent, register-tiled) kernel equals the constant-geometry kernel,
+    # a different dataflow with canonical arithmetic; the grouped variants on a slab
+    assert torch.equal(plan.poly_mult(a, b, variant="cg"), c)
+    for v in ("cg8", "cg8_padded"):
         assert torch.equal(plan.poly_mult(a[:512], b[:512], variant=v), c[:512]), v
     # outputs canonical
     assert int(plan.to_host(c).max()) < q
