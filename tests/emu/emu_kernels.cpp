@@ -88,9 +88,9 @@ int fused_ntt_emu(const HostTables& t, int mode, const u64* in, u64* out) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
-  const Arith<E> ar = h_make_arith<E>(t);
-  const std::vector<Tw> tab = h_tw_table<E>(mode == 2 ? t.psi_inv_brv : t.psi_brv, t.q);
-  const std::vector<Tw> twist = h_tw_table<E>(mode == 1 ? t.psi_inv_pow : t.psi_pow, t.q);
+  Arith<E> ar = h_make_arith<E>(t);
+  if (mode == 2) ar.ninv_w1 = ar.ninv;                      // cyc_inv_brv[1] = 1 (as launch_nttf_t does)
+  const std::vector<Tw> tab = h_tw_table<E>(mode == 2 ? t.cyc_inv_brv : (mode == 1 ? t.cyc_brv : t.psi_brv), t.q);
   std::vector<Tw> lds_tab(tab.begin() + Cfg::lds_tw_lo(), tab.begin() + Cfg::lds_tw_hi());
   std::vector<E> lds(Cfg::lds_elems());
   struct Regs { E x[Cfg::R]; };
@@ -111,12 +111,12 @@ int fused_ntt_emu(const HostTables& t, int mode, const u64* in, u64* out) {
         for (u32 tau = 0; tau < T; ++tau) ex_load<E, Cfg, p - 1, p - 1>(x[tau].x, tau, lds.data());
       }
     });
-    for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) { const u32 j = Cfg::jidx(0, tau, r); out[j] = mul_tw(x[tau].x[r], twist[j], ar.q); }
+    for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) out[Cfg::jidx(0, tau, r)] = x[tau].x[r];
     return 0;
   }
   for (u32 tau = 0; tau < T; ++tau) for (int r = 0; r < Cfg::R; ++r) {
     const u32 j = Cfg::jidx(0, tau, r);
-    x[tau].x[r] = mode == 1 ? Pol::load(mul_tw_lazy((E)in[j], twist[j], ar.q), ar) : Pol::load((E)in[j], ar);
+    x[tau].x[r] = (LAZY && r >= Cfg::R / 2) ? (E)in[j] : Pol::load((E)in[j], ar);     // as ntt_fused_kernel: only the "u" half is reduced
   }
   static_for<0, Cfg::PHASES>([&](auto p_) {
     constexpr int p = decltype(p_)::value;

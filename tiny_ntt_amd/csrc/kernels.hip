@@ -280,14 +280,15 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 
 // Standalone transforms on the register-tiled machinery, natural order in and out:
 //   FNTT_TWIST_FWD   X[k] = sum_i x[i] psi^(i(2k+1))   = twist + cg_ntt = forward_ntt_bench (benchmark_ntt_60bit.cpp:161-165)
-//   FNTT_CYCLIC_FWD  cg_ntt(x, omega=psi^2)            (cg_ntt.py:29-65)  = the above on x[i] psi^-i
-//   FNTT_CYCLIC_INV  cg_intt(X, omega=psi^2)           (cg_ntt.py:68-75)  = merged inverse, then * psi^i
-// The merged transform produces / consumes bit-reversed order in the last phase's register layout;
+//   FNTT_CYCLIC_FWD  cg_ntt(x, omega=psi^2)            (cg_ntt.py:29-65)
+//   FNTT_CYCLIC_INV  cg_intt(X, omega=psi^2)           (cg_ntt.py:68-75)
+// All three are the same merged Cooley-Tukey / Gentleman-Sande butterflies; only the twiddle table differs: the
+// negacyclic one (psi_brv: factorisation tree of x^n + 1) or the cyclic one (cyc_brv / cyc_inv_brv: tree of x^n - 1,
+// see HostTables).  The merged transform produces / consumes bit-reversed order in the last phase's register layout;
 // one extra LDS transpose through a natural-order image turns that into unit-stride HBM accesses.
 template <typename E, int LOGN, int LPT, bool LAZY, int MODE>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))
-ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab, const typename TwOf<E>::type* __restrict__ twist,
-                 const E* __restrict__ in, E* __restrict__ out, u32 batch) {
+ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab, const E* __restrict__ in, E* __restrict__ out, u32 batch) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
@@ -298,13 +299,28 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) lds_tab[i] = tab[Cfg::lds_tw_lo() + i];
   __syncthreads();
   constexpr int LAST = Cfg::PHASES - 1;
-  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
-    const size_t off = (size_t)row << LOGN;
+  // The next row's input is requested as soon as the current one has been consumed, so the HBM latency of row k+1
+  // hides behind the arithmetic of row k (persistent workgroup, like the product kernel).
+  E xn[Cfg::R];
+  u32 row = blockIdx.x;
+  if (row < batch) {
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, row, tau, r);
+  }
+  for (; row < batch; row += gridDim.x) {
+    const u32 next = row + gridDim.x;
     E x[Cfg::R];
+#pragma unroll
+    for (int r = 0; r < Cfg::R; ++r) x[r] = xn[r];
+    sched_fence();
+    if (MODE != FNTT_CYCLIC_INV && next < batch) {
+#pragma unroll
+      for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tau, r);
+    }
+    sched_fence();
     if (MODE == FNTT_CYCLIC_INV) {
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) x[r] = Pol::load(in[off + Cfg::jidx(0, tau, r)], ar);
-      __syncthreads();
+      for (int r = 0; r < Cfg::R; ++r) x[r] = Pol::load(x[r], ar);
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))] = x[r];
       __syncthreads();
@@ -313,18 +329,21 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
       Tw pre[Cfg::NPRE];
       tw_prefetch<E, Cfg>(pre, tau, tab);
       const TwRefs<E> tw = {tab, lds_tab, pre};
-      inverse_all<E, Cfg, Pol>(x, tau, tw, ar, lds, []() {});
+      // the inverse starts with the thread-private phase (28 registers of twiddles): the prefetch goes after it,
+      // as in the product kernel
+      inverse_all<E, Cfg, Pol>(x, tau, tw, ar, lds, [&]() {
+        if (next < batch) {
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) {
-        const u32 j = Cfg::jidx(0, tau, r);
-        out[off + j] = mul_tw(x[r], twist[j], ar.q);             // * psi^j
-      }
+          for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tau, r);
+        }
+      });
+      st_result<E, Cfg>(out, row, tau, x);
     } else {
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) {
-        const u32 j = Cfg::jidx(0, tau, r);
-        const E v = in[off + j];
-        x[r] = (MODE == FNTT_CYCLIC_FWD) ? Pol::load(mul_tw_lazy(v, twist[j], ar.q), ar) : Pol::load(v, ar);   // * psi^-j
+      for (int r = 0; r < Cfg::R / 2; ++r) x[r] = Pol::load(x[r], ar);                 // the other half is multiplied first
+      if (!LAZY) {
+#pragma unroll
+        for (int r = Cfg::R / 2; r < Cfg::R; ++r) x[r] = Pol::load(x[r], ar);
       }
       forward_all<E, Cfg, Pol>(x, tau, tab, lds_tab, ar, lds);
       __syncthreads();
@@ -333,7 +352,8 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
         lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[r], ar) : x[r];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) out[off + Cfg::jidx(0, tau, r)] = lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
+      for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
+      st_result<E, Cfg>(out, row, tau, x);
     }
     __syncthreads();
   }
@@ -346,10 +366,11 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw);
   const PlanView<E> pv = make_view<E>(p);
   const void* kern = nullptr;
-  const Tw *tab = nullptr, *twist = nullptr;
-  if (mode == FNTT_TWIST_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_TWIST_FWD>; tab = pv.psi_brv; twist = pv.psi_pow; }
-  else if (mode == FNTT_CYCLIC_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_FWD>; tab = pv.psi_brv; twist = pv.psi_inv_pow; }
-  else { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_INV>; tab = pv.psi_inv_brv; twist = pv.psi_pow; }
+  const Tw* tab = nullptr;
+  Arith<E> ar = pv.ar;
+  if (mode == FNTT_TWIST_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_TWIST_FWD>; tab = pv.psi_brv; }
+  else if (mode == FNTT_CYCLIC_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_FWD>; tab = pv.cyc_brv; }
+  else { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_INV>; tab = pv.cyc_inv_brv; ar.ninv_w1 = ar.ninv; }   // cyc_inv_brv[1] = 1
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -359,9 +380,8 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
   const u32 grid = (u32)(batch < resident ? batch : resident);
-  Arith<E> ar = pv.ar;
   const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
-  void* args[] = {&ar, &tab, &twist, &in_, &out_, &b32};
+  void* args[] = {&ar, &tab, &in_, &out_, &b32};
   return hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
 }
 

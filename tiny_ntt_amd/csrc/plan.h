@@ -31,7 +31,9 @@ struct tn_plan {
   void* d_omega_pow = nullptr;     // [n/2] omega^j   (cg_ntt.py:51,54 — pow(omega_s, i//k) = omega^(k*(i//k)))
   void* d_omega_inv_pow = nullptr; // [n/2] omega^-j
   void* d_psi_pow = nullptr;       // [n]   psi^i     (twist, cg_ntt.py:82-83)
-  void* d_psi_inv_pow = nullptr;   // [n]   psi^-i  (pre-twist of the fused cyclic forward transform)
+  void* d_psi_inv_pow = nullptr;   // [n]   psi^-i
+  void* d_cyc_brv = nullptr;       // [n]   merged twiddles of the cyclic transform (HostTables::cyc_brv): fused cg_ntt
+  void* d_cyc_inv_brv = nullptr;   // [n]   their inverses: fused cg_intt
   void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
   void* d_scratch = nullptr;       // host-entry staging (grown on demand)
   size_t scratch_bytes = 0;
@@ -53,6 +55,8 @@ template <typename E> struct PlanView {
   const Tw* psi_pow;
   const Tw* psi_inv_ninv;
   const Tw* psi_inv_pow;
+  const Tw* cyc_brv;
+  const Tw* cyc_inv_brv;
 };
 
 template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
@@ -67,6 +71,7 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
   v.omega_pow = (const Tw*)p->d_omega_pow; v.omega_inv_pow = (const Tw*)p->d_omega_inv_pow;
   v.psi_pow = (const Tw*)p->d_psi_pow; v.psi_inv_ninv = (const Tw*)p->d_psi_inv_ninv;
   v.psi_inv_pow = (const Tw*)p->d_psi_inv_pow;
+  v.cyc_brv = (const Tw*)p->d_cyc_brv; v.cyc_inv_brv = (const Tw*)p->d_cyc_inv_brv;
   return v;
 }
 

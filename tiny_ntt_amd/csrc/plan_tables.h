@@ -14,6 +14,10 @@ struct HostTables {
   u32 fold_c = 0;
   u64 n_inv = 0, ninv_w1 = 0;
   std::vector<u64> psi_pow, psi_inv_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
+  // merged twiddles of the CYCLIC transform (x^n - 1 factorisation tree): node m+i (m = 2^s nodes at level s) splits
+  // x^(n/m) - zeta with sqrt(zeta) = psi^(brv(m+i) - n/(2m)); same butterflies, same bit-reversed output order as
+  // the negacyclic table psi_brv, so cg_ntt / cg_intt run on the fused kernel without a pre- or post-twist
+  std::vector<u64> cyc_brv, cyc_inv_brv;
 };
 
 inline u32 h_brv(u32 v, u32 bits) {
@@ -90,6 +94,14 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
     t.psi_brv[i] = t.psi_pow[h_brv(i, logn)];
     t.psi_inv_brv[i] = psi_inv_pow[h_brv(i, logn)];
     t.psi_inv_ninv[i] = h_mulmod(psi_inv_pow[i], t.n_inv, q);
+  }
+  t.cyc_brv.assign(n, 1); t.cyc_inv_brv.assign(n, 1);
+  for (u32 i = 1; i < n; ++i) {
+    u32 m = 1;
+    while (2 * m <= i) m *= 2;
+    const u32 e = h_brv(i, logn) - n / (2 * m);
+    t.cyc_brv[i] = t.psi_pow[e];
+    t.cyc_inv_brv[i] = psi_inv_pow[e];
   }
   u64 w = 1, wi = 1;
   for (u32 j = 0; j < n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
