@@ -138,7 +138,8 @@ tn_status tn_twisted_ntt_forward_dev(tn_plan *plan, const void *in, void *out, s
 /*
  * Untwisted (CYCLIC) product: cg_ntt(a), cg_ntt(b), pointwise, cg_intt with omega = psi^2 —
  * python_poly_mult (test/cocotb_tests/test_ntt_poly_mult.py:38-43), i.e. what the reference's
- * RTL top level / RoCC accelerator computes.  CG variants only.
+ * RTL top level / RoCC accelerator computes.  TN_VARIANT_FUSED runs the fused
+ * product kernel on the twiddle tables of the x^n - 1 factorisation tree (no twist anywhere).
  */
 tn_status tn_cyclic_poly_mult_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch,
                                   tn_variant variant, void *stream);

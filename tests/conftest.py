@@ -172,11 +172,11 @@ class Emu:
         L.emu_pointwise_lazy64.argtypes = [u64, u64, u64]; L.emu_pointwise_lazy64.restype = u64
         L.emu_fold32.argtypes = [u32, u32]; L.emu_fold32.restype = u32
 
-    def fused(self, n, q, psi, a, b, canonical=False):
+    def fused(self, n, q, psi, a, b, canonical=False, cyclic=False):
         a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
         a2, b2 = np.atleast_2d(a), np.atleast_2d(b)
         c = np.empty_like(a2)
-        rc = self.lib.emu_fused_poly_mult(n, q, psi, int(canonical), p64(a2), p64(b2), p64(c), a2.shape[0])
+        rc = self.lib.emu_fused_poly_mult(n, q, psi, int(canonical) | (2 if cyclic else 0), p64(a2), p64(b2), p64(c), a2.shape[0])
         assert rc == 0, rc
         return c.reshape(a.shape)
 

@@ -15,12 +15,14 @@ using namespace tn;
 namespace {
 
 template <typename E, int LOGN, int LPT, bool LAZY>
-int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch) {
+int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
-  const Arith<E> ar = h_make_arith<E>(t);
-  const std::vector<Tw> psi_brv = h_tw_table<E>(t.psi_brv, t.q), psi_inv_brv = h_tw_table<E>(t.psi_inv_brv, t.q);
+  Arith<E> ar = h_make_arith<E>(t);
+  if (cyclic) ar.ninv_w1 = ar.ninv;                        // as launch_fused_t: product in Z_q[x]/(x^n - 1)
+  const std::vector<Tw> psi_brv = h_tw_table<E>(cyclic ? t.cyc_brv : t.psi_brv, t.q),
+                        psi_inv_brv = h_tw_table<E>(cyclic ? t.cyc_inv_brv : t.psi_inv_brv, t.q);
   std::vector<E> lds(Cfg::lds_elems());
   struct Regs { E x[Cfg::R]; };
   std::vector<Regs> xa(Cfg::THREADS), xb(Cfg::THREADS);
@@ -145,13 +147,13 @@ int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
 }
 
 template <typename E, bool LAZY>
-int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch) {
+int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch, bool cyclic) {
   switch (t.logn) {
-    case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch);
-    case 9: return fused_polymul_emu<E, 9, 3, LAZY>(t, a, b, c, batch);
-    case 10: return fused_polymul_emu<E, 10, 3, LAZY>(t, a, b, c, batch);
-    case 11: return fused_polymul_emu<E, 11, 3, LAZY>(t, a, b, c, batch);
-    case 12: return fused_polymul_emu<E, 12, 3, LAZY>(t, a, b, c, batch);
+    case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch, cyclic);
+    case 9: return fused_polymul_emu<E, 9, 3, LAZY>(t, a, b, c, batch, cyclic);
+    case 10: return fused_polymul_emu<E, 10, 3, LAZY>(t, a, b, c, batch, cyclic);
+    case 11: return fused_polymul_emu<E, 11, 3, LAZY>(t, a, b, c, batch, cyclic);
+    case 12: return fused_polymul_emu<E, 12, 3, LAZY>(t, a, b, c, batch, cyclic);
     default: return 7;
   }
 }
@@ -229,12 +231,14 @@ bool params_ok(u32 n, u64 q, u64 psi) {
 extern "C" {
 
 // 0 ok, 2 bad params, 7 unsupported n.  Coefficients travel as uint64 regardless of lane width.
-int emu_fused_poly_mult(uint32_t n, uint64_t q, uint64_t psi, int force_canonical, const uint64_t* a, const uint64_t* b,
+// flags: bit 0 = canonical policy, bit 1 = cyclic product (x^n - 1) instead of negacyclic.
+int emu_fused_poly_mult(uint32_t n, uint64_t q, uint64_t psi, int flags, const uint64_t* a, const uint64_t* b,
                         uint64_t* c, size_t batch) {
   if (!params_ok(n, q, psi)) return 2;
-  const HostTables t = h_build_tables(n, q, psi, !force_canonical);
-  if (t.elem_bytes == 8) return t.lazy ? fused_dispatch<u64, true>(t, a, b, c, batch) : fused_dispatch<u64, false>(t, a, b, c, batch);
-  return t.lazy ? fused_dispatch<u32, true>(t, a, b, c, batch) : fused_dispatch<u32, false>(t, a, b, c, batch);
+  const bool cyc = (flags & 2) != 0;
+  const HostTables t = h_build_tables(n, q, psi, !(flags & 1));
+  if (t.elem_bytes == 8) return t.lazy ? fused_dispatch<u64, true>(t, a, b, c, batch, cyc) : fused_dispatch<u64, false>(t, a, b, c, batch, cyc);
+  return t.lazy ? fused_dispatch<u32, true>(t, a, b, c, batch, cyc) : fused_dispatch<u32, false>(t, a, b, c, batch, cyc);
 }
 
 // mode: 0 twist + forward (natural out), 1 cg_ntt, 2 cg_intt — the register-tiled standalone transforms

@@ -164,6 +164,26 @@ def test_fused_standalone_transforms_emulation_matches_golden(emu, golden, tag, 
     assert np.array_equal(emu.fused_ntt(g.n, g.q, g.psi, 0, g["lcg12_mul_a"], canonical), g["lcg1_fwd"])        # forward_ntt_bench
 
 
+@pytest.mark.parametrize("tag", ["P256", "P1024", "P4096", "P4096_60"])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_fused_cyclic_product_emulation(emu, oracle, tag, canonical):
+    """The fused product kernel on the x^n - 1 twiddle tables = python_poly_mult (test_ntt_poly_mult.py:38-43):
+    cg_ntt, cg_ntt, pointwise, cg_intt with omega = psi^2 and no twist."""
+    n, q, psi = PARAMS[tag]
+    omega = psi * psi % q
+    rng = np.random.default_rng(7)
+    word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1
+    a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
+    a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b[1] = word          # any word is taken mod q
+    a[2] = 0; a[2, n - 1] = 1; b[2] = 0; b[2, 1] = 1                                        # x^(n-1) * x = +1 (no sign flip)
+    got = emu.fused(n, q, psi, a, b, canonical, cyclic=True)
+    for r in range(3):
+        A, B = oracle.cg_ntt(a[r], omega, q), oracle.cg_ntt(b[r], omega, q)
+        C = np.array([int(x) * int(y) % q for x, y in zip(A, B)], dtype=np.uint64)
+        assert np.array_equal(got[r], oracle.cg_intt(C, omega, q)), (tag, r)
+    assert got[2][0] == 1 and not got[2][1:].any()
+
+
 @pytest.mark.parametrize("n", [512, 2048])
 def test_fused_standalone_transforms_other_sizes(emu, oracle, n):
     from tiny_ntt_amd import numtheory

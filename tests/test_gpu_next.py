@@ -32,7 +32,7 @@ def test_cyclic_product_matches_rtl_reference_model(eng, oracle, tag):
     rng = np.random.default_rng(99)
     a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
     a[0] = 0; a[0, :3] = [1, 2, 3]; b[0] = 0; b[0, :2] = [5, 1]                      # chipyard/ntt-test.c KAT
-    for v in ("cg", "cg8", "cg8_padded"):
+    for v in ("cg", "cg8", "cg8_padded") + (("fused", "auto") if plan.has_fused else ()):
         got = plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
         for r in range(3):
             assert np.array_equal(got[r], cyclic_oracle(oracle, a[r], b[r], q, plan.omega)), (tag, v, r)
@@ -42,8 +42,15 @@ def test_cyclic_product_matches_rtl_reference_model(eng, oracle, tag):
     xm = np.zeros(n, dtype=plan.dtype); xm[n - 1] = 1
     x1 = np.zeros(n, dtype=plan.dtype); x1[1] = 1
     assert plan.cyclic_poly_mult(xm, x1)[0] == 1 and plan.poly_mult(xm, x1)[0] == q - 1
-    with pytest.raises(eng.TinyNttError, match="only the CG variants"):
-        plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant="fused")
+    if not plan.has_fused:
+        with pytest.raises(eng.TinyNttError, match="fused kernel not built"):
+            plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant="fused")
+    else:                                            # canonical policy + a larger batch through the persistent kernel
+        cplan = eng.get_plan(n, q, psi, 0, eng.PLAN_FORCE_CANONICAL)
+        aa = rng.integers(0, q, (300, n), dtype=np.uint64).astype(plan.dtype); bb = rng.integers(0, q, (300, n), dtype=np.uint64).astype(plan.dtype)
+        ref = plan.cyclic_poly_mult(aa, bb, variant="cg")
+        assert np.array_equal(plan.cyclic_poly_mult(aa, bb, variant="fused"), ref)
+        assert np.array_equal(cplan.cyclic_poly_mult(aa, bb, variant="fused"), ref)
 
 
 @pytest.mark.parametrize("tag", ["P256", "P1024", "P4096_60"])

@@ -204,9 +204,14 @@ extern "C" tn_status tn_cyclic_poly_mult_dev(tn_plan* p, const void* a, const vo
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_cyclic_poly_mult_dev");
   if (st) return st;
   TN_ON_DEVICE(p);
-  if (variant == TN_VARIANT_AUTO) variant = TN_VARIANT_CG;
+  if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
+  if (variant == TN_VARIANT_FUSED) {
+    if (!p->has_fused) return fail(TN_EUNSUPPORTED, "tn_cyclic_poly_mult_dev: fused kernel not built for this n; use TN_VARIANT_CG");
+    TN_HIP(launch_polymul_fused(p, a, b, c, batch, pick_stream(p, stream), /*cyclic=*/true));
+    return TN_OK;
+  }
   CgSel sel;
-  if (!cg_sel(variant, &sel)) return fail(TN_EUNSUPPORTED, "tn_cyclic_poly_mult_dev: only the CG variants implement the untwisted product");
+  if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, "tn_cyclic_poly_mult_dev: unknown variant");
   TN_HIP(launch_cg(p, CG_CYCLIC_POLYMUL, sel.group, sel.padded, a, b, c, nullptr, batch, pick_stream(p, stream)));
   return TN_OK;
 }

@@ -419,7 +419,7 @@ static int fused_lpt(u32 logn) {
 bool fused_supported(u32 logn, int) { return fused_lpt(logn) != 0; }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
-static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0)) * sizeof(E) +
                            (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type);
@@ -435,28 +435,32 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
   const u32 grid = (u32)(batch < resident ? batch : resident);
   const PlanView<E> pv = make_view<E>(p);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, pv.ar, pv.psi_brv, pv.psi_inv_brv, (const E*)a, (const E*)b,
-                     (E*)c, (u32)batch);
+  // cyclic = product in Z_q[x]/(x^n - 1) (python_poly_mult, test_ntt_poly_mult.py:38-43): same kernel, twiddle
+  // tables of the x^n - 1 factorisation tree (HostTables::cyc_brv), whose inverse table has entry 1 equal to 1
+  Arith<E> ar = pv.ar;
+  if (cyclic) ar.ninv_w1 = ar.ninv;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
+                     cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch);
   return hipGetLastError();
 }
 
 template <typename E, bool LAZY>
-static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   switch (p->logn) {
-    case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s);
-    case 9: return launch_fused_t<E, 9, 3, LAZY>(p, a, b, c, batch, s);
-    case 10: return launch_fused_t<E, 10, TN_FUSED_LPT10, LAZY>(p, a, b, c, batch, s);
-    case 11: return launch_fused_t<E, 11, 3, LAZY>(p, a, b, c, batch, s);
-    case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s);
+    case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s, cyclic);
+    case 9: return launch_fused_t<E, 9, 3, LAZY>(p, a, b, c, batch, s, cyclic);
+    case 10: return launch_fused_t<E, 10, TN_FUSED_LPT10, LAZY>(p, a, b, c, batch, s, cyclic);
+    case 11: return launch_fused_t<E, 11, 3, LAZY>(p, a, b, c, batch, s, cyclic);
+    case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s, cyclic);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s) {
+hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   if (batch == 0) return hipSuccess;
   if (p->elem_bytes == 8)
-    return p->lazy ? launch_fused_e<u64, true>(p, a, b, c, batch, s) : launch_fused_e<u64, false>(p, a, b, c, batch, s);
-  return p->lazy ? launch_fused_e<u32, true>(p, a, b, c, batch, s) : launch_fused_e<u32, false>(p, a, b, c, batch, s);
+    return p->lazy ? launch_fused_e<u64, true>(p, a, b, c, batch, s, cyclic) : launch_fused_e<u64, false>(p, a, b, c, batch, s, cyclic);
+  return p->lazy ? launch_fused_e<u32, true>(p, a, b, c, batch, s, cyclic) : launch_fused_e<u32, false>(p, a, b, c, batch, s, cyclic);
 }
 
 const char* fused_kernel_name(const tn_plan* p) {

@@ -79,7 +79,7 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
 bool fused_supported(u32 logn, int elem_bytes);
 const char* fused_kernel_name(const tn_plan* p);
 const char* cg_kernel_name(const tn_plan* p, int group, bool padded);
-hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
+hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic = false);
 hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s);
 hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
                      void* trace, size_t batch, hipStream_t s);

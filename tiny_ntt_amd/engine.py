@@ -250,7 +250,7 @@ class Plan:
             return res[0] if squeeze else res
         return c
 
-    def cyclic_poly_mult(self, a, b, variant="cg", out=None, stream=None):
+    def cyclic_poly_mult(self, a, b, variant="auto", out=None, stream=None):
         """Untwisted product forward->pointwise->inverse: python_poly_mult (test_ntt_poly_mult.py:38-43)."""
         return self._binary_dev(self._lib.tn_cyclic_poly_mult_dev, a, b, out, stream, _variant(variant))
 
