@@ -165,7 +165,7 @@ TN_HD u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu, int k) {
 // < 2^k + (x >> k) * c.  Written on the high dword so it is 2 two-cycle ops + one v_mad_u64_u32.
 TN_HD u64 fold(u64 x, int k, u32 c) {
   const u32 top = (u32)(x >> 32) >> (k - 32);
-  const u64 lowmask = (((u64)1) << k) - 1;
+  const u64 lowmask = ((u64)((1u << (k - 32)) - 1u) << 32) | 0xFFFFFFFFull;   // k >= 32: the low dword needs no masking
   return (x & lowmask) + (u64)top * c;
 }
 
