@@ -106,8 +106,17 @@ def cpu_baseline(budget_s=12.0):
                 raise RuntimeError("parallel baseline run failed")
             per = [float(dict(l.split("=", 1) for l in o.splitlines() if "=" in l and " " not in l)["avg_ns"]) for o in outs]
             allcore = sum(1e9 / ns for ns in per)
+            others = {}                                  # the same benchmark's other builds, one thread, ~1 s each
+            for k in ("scalar", "avx2", "avx512"):
+                e2 = os.path.join(os.path.dirname(exe), os.path.basename(exe).rsplit("_", 1)[0] + "_" + k) if kind == "reference" else None
+                if e2 and e2 != exe and os.path.exists(e2):
+                    try:
+                        others[k] = round(1e9 / run(e2, max(100, int(1e9 / (probe * 1.5)))), 1)
+                    except Exception as e:
+                        sys.stderr.write(f"[bench] {e2} skipped: {e}\n")
             return {"value": round(allcore, 1), "unit": "poly-mults/s", "cores": cores, "kind": kind,
                     "simd": simd, "single_thread_value": round(1e9 / single_ns, 1), "single_thread_avg_ns": round(single_ns),
+                    "single_thread_other_builds": others,
                     "sample": f"{os.path.basename(exe)}: same pair make_poly(1)xmake_poly(2) every rep (reference main loop); "
                               f"1 thread x {reps1} reps, then {cores} processes x {repsN} reps ({wall:.1f} s wall)"}
         except Exception as e:                                     # e.g. SIGILL on a host without AVX-512
