@@ -46,6 +46,9 @@
 #define TN_FUSED_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (4 -> <= 128 VGPRs)
 #endif
 
+#ifndef TN_EX_LOOSE
+#define TN_EX_LOOSE 0            // 1: wave-local transposes without the outer scheduling fences (measured 1 % slower on MI355X)
+#endif
 #ifdef TN_MARKS
 #define TN_MARK(n) asm volatile("; TNMARK " n)
 #else
@@ -63,11 +66,15 @@ namespace tn {
 template <typename E, typename Cfg, int EX, int FROM, int TO>
 __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
   if constexpr (Cfg::ex_wave_local(EX)) {
+#if !TN_EX_LOOSE
     __builtin_amdgcn_wave_barrier();
+#endif
     ex_store<E, Cfg, EX, FROM>(x, tau, lds);
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();     // lanes read what OTHER lanes of the wave wrote: loads may not move above the stores
     ex_load<E, Cfg, EX, TO>(x, tau, lds);
+#if !TN_EX_LOOSE
     __builtin_amdgcn_wave_barrier();
+#endif
   } else {
 #if TN_ABL_NO_BARRIER
     __builtin_amdgcn_wave_barrier();
