@@ -147,9 +147,28 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        tdist.init_process_group(backend)
     dev = torch.device("cuda", dev_index)
+    if world > 1:
+        if backend == "nccl":
+            # the only collectives of this job are the timing barrier and a max-reduce of two floats: if RCCL cannot
+            # come up on this node, run that control plane over gloo instead of losing the measurement
+            try:
+                tdist.init_process_group(backend)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                assert int(probe.item()) == world
+            except Exception as e:
+                sys.stderr.write(f"[bench] RCCL control plane unavailable ({type(e).__name__}: {str(e)[:200]}); using gloo for barrier/max-reduce\n")
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                tdist.init_process_group(backend)
+        else:
+            tdist.init_process_group(backend)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     plan = engine.Plan(N_COEFF, Q, PSI, device=dev_index)
