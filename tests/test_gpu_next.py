@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, PARAMS
+from conftest import GOLDEN, PARAMS, REF_CHECKSUMS
 
 pytestmark = pytest.mark.gpu
 
@@ -134,3 +134,34 @@ def test_rocc_session_protocol(eng, oracle, mode):
     got = np.array(s.multiply(ra, rb), dtype=np.uint64)
     ref = cyclic_oracle(oracle, ra, rb, q, psi * psi % q) if mode == "cyclic" else oracle.poly_mult(ra, rb, q, psi)
     assert np.array_equal(got, ref)
+
+
+def test_benchmark_cli_twin_reports_like_the_reference_binary():
+    """tools/benchmark_ntt_gpu.c: the software_benchmark CLI over the C ABI (plain C99).  Same keys as the reference
+    binary (compiled unmodified under oracle/_ref), same checksums for the reference's own input pair (row 0)."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tiny_ntt_amd", "lib", "benchmark_ntt_gpu")
+    assert os.path.exists(exe), "make -C tiny_ntt_amd/csrc builds it"
+
+    def kv(out):
+        return dict(l.split("=", 1) for l in out.splitlines() if "=" in l and " " not in l)
+
+    r = subprocess.run([exe, "--reps", "3", "--batch", "300", "--check"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = kv(r.stdout)
+    assert int(got["forward_ntt_checksum"]) == REF_CHECKSUMS["P4096_60"][0] and int(got["checksum"]) == REF_CHECKSUMS["P4096_60"][1]
+    assert "check=ok rows=4" in r.stdout
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "benchmark_ntt_60bit_scalar")
+    if os.path.exists(ref_exe):                       # built from the reference sources in the build container; travels with the snapshot
+        ref = kv(subprocess.run([ref_exe, "--reps", "1"], stdout=subprocess.PIPE, text=True, timeout=300).stdout)
+        assert set(ref) <= set(got), (sorted(ref), sorted(got))
+        assert ref["checksum"] == got["checksum"] and ref["forward_ntt_checksum"] == got["forward_ntt_checksum"]
+    # the 24-bit benchmark configuration (CMakeLists.txt:5-7) through the same binary
+    n, q, psi = PARAMS["P4096"]
+    r = subprocess.run([exe, "--reps", "2", "--batch", "64", "--n", str(n), "--q", str(q), "--psi", str(psi), "--check"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = kv(r.stdout)
+    assert int(got["forward_ntt_checksum"]) == REF_CHECKSUMS["P4096"][0] and int(got["checksum"]) == REF_CHECKSUMS["P4096"][1]
+    assert subprocess.run([exe, "--bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 2
