@@ -29,6 +29,36 @@ REF_CHECKSUMS = {
 }
 
 
+def is_prime(m):
+    if m < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if m % p == 0:
+            return m == p
+    d, s = m - 1, 0
+    while d % 2 == 0:
+        d //= 2; s += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, m)
+        if x in (1, m - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % m
+            if x == m - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def ntt_prime_below(limit, n):
+    """largest prime q < limit with q = 1 (mod 2n)"""
+    q = (limit - 2) // (2 * n) * (2 * n) + 1
+    while not is_prime(q):
+        q -= 2 * n
+    return q
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -164,6 +164,31 @@ def test_fused_standalone_transforms_emulation_matches_golden(emu, golden, tag, 
     assert np.array_equal(emu.fused_ntt(g.n, g.q, g.psi, 0, g["lcg12_mul_a"], canonical), g["lcg1_fwd"])        # forward_ntt_bench
 
 
+@pytest.mark.parametrize("n", [256, 1024])
+def test_fused_emulation_modulus_sweep(emu, oracle, n):
+    """CPU stepping of the fused kernel over moduli of 20..62 bits, lazy (q = 2^k - c) and canonical policies
+    (the GPU twin of this sweep is test_gpu_parity.py::test_modulus_sweep_every_word_size_both_policies)."""
+    from conftest import ntt_prime_below
+    from tiny_ntt_amd import numtheory
+    lazy = set()
+    for k in (20, 26, 31, 32, 33, 36, 41, 47, 52, 57, 60, 61, 62):
+        for limit in (2 ** k, int(0.71 * 2 ** k)):
+            q = ntt_prime_below(limit, n)
+            psi = numtheory.find_psi(n, q)
+            if emu.lib.emu_is_lazy(n, q, psi) == 1:
+                lazy.add(q.bit_length())
+            rng = np.random.default_rng(k)
+            word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1
+            a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
+            a[0], b[0] = q - 1, q - 1
+            a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b[1] = word
+            assert np.array_equal(emu.fused(n, q, psi, a, b), oracle.poly_mult(a, b, q, psi)), (n, q)
+            X = emu.fused_ntt(n, q, psi, 1, a[1])
+            assert np.array_equal(X, oracle.cg_ntt(a[1], psi * psi % q, q)), (n, q)
+            assert np.array_equal(emu.fused_ntt(n, q, psi, 2, X), a[1] % np.uint64(q)), (n, q)
+    assert {26, 41, 47, 52, 57, 60} <= lazy and not ({61, 62} & lazy)
+
+
 @pytest.mark.parametrize("tag", ["P256", "P1024", "P4096", "P4096_60"])
 @pytest.mark.parametrize("canonical", [False, True])
 def test_fused_cyclic_product_emulation(emu, oracle, tag, canonical):

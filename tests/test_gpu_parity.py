@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import PARAMS, REF_CHECKSUMS
+from conftest import PARAMS, REF_CHECKSUMS, ntt_prime_below
 
 pytestmark = pytest.mark.gpu
 
@@ -155,6 +155,34 @@ def test_generic_moduli_run_canonical(eng, oracle):
         ref = oracle.poly_mult(a, b, q, psi)
         for v in variants_of(plan):
             assert np.array_equal(plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64), ref), (q, v)
+
+
+@pytest.mark.parametrize("n", [256, 4096])
+def test_modulus_sweep_every_word_size_both_policies(eng, oracle, n):
+    """Moduli from 20 to 62 bits: q = 2^k - c (lazy policy where the bounds allow, checked per plan) and primes far from
+    a power of two (canonical policy), 32- and 64-bit lanes, fused and constant-geometry kernels, against the oracle."""
+    from tiny_ntt_amd import numtheory
+    seen_lazy, seen_canon = set(), set()
+    for k in (20, 26, 31, 32, 33, 36, 41, 47, 52, 57, 60, 61, 62):
+        for limit in (2 ** k, int(0.71 * 2 ** k)):
+            q = ntt_prime_below(limit, n)
+            psi = numtheory.find_psi(n, q)
+            plan = eng.Plan(n, q, psi)
+            (seen_lazy if plan.is_lazy else seen_canon).add(q.bit_length())
+            rng = np.random.default_rng(k)
+            word = 2 ** (8 * plan.elem_bytes) - 1
+            a = rng.integers(0, q, (6, n), dtype=np.uint64); b = rng.integers(0, q, (6, n), dtype=np.uint64)
+            a[0], b[0] = q - 1, q - 1
+            a[1] = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b[1] = word
+            ref = oracle.poly_mult(a, b, q, psi)
+            for v in ("fused", "cg"):
+                got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
+                assert np.array_equal(got, ref), (n, q, v, plan.is_lazy)
+            A = plan.ntt_forward(a.astype(plan.dtype), variant="fused").astype(np.uint64)
+            assert np.array_equal(A[1], oracle.cg_ntt(a[1], plan.omega, q)), (n, q)
+            assert np.array_equal(plan.ntt_inverse(A.astype(plan.dtype), variant="fused").astype(np.uint64), a % np.uint64(q)), (n, q)
+            plan.close()
+    assert {26, 41, 47, 52, 57, 60} <= seen_lazy and {20, 31, 32, 33, 36, 61, 62} <= seen_canon, (seen_lazy, seen_canon)
 
 
 def test_sizes_without_a_fused_kernel_use_cg(eng, oracle):
