@@ -27,7 +27,7 @@ STATE_IDLE, STATE_DONE = 0, 10          # debug_state field, bits [7:4] (ntt-tes
 
 
 class NttRoccSession:
-    def __init__(self, n: int, q: int, psi: int, device: int = 0, mode: str = "cyclic", variant: str = "cg"):
+    def __init__(self, n: int, q: int, psi: int, device: int = 0, mode: str = "cyclic", variant: str = "auto"):
         if mode not in ("cyclic", "negacyclic"):
             raise ValueError("mode must be 'cyclic' or 'negacyclic'")
         self.plan = engine.get_plan(n, q, psi, device)
