@@ -32,3 +32,12 @@ for name, fn in (("cg_ntt fused", lambda: plan.ntt_forward(x, variant="fused", o
     rows = 8192 if name.endswith(" cg") else B
     ms = ev0.elapsed_time(ev1) / 5
     print(f"{name:18s} {ms:8.3f} ms  {rows/ms*1e3/1e6:8.2f} M NTT/s  {rows*2*n*8/ms/1e6:7.0f} GB/s (2nw bytes)", flush=True)
+
+# measured HBM copy bandwidth on this box ("also record measured copy bandwidth"): 2 GiB device-to-device
+src = torch.empty(2 << 30, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
+dst.copy_(src); torch.cuda.synchronize()
+ev0.record()
+for _ in range(10): dst.copy_(src)
+ev1.record(); torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / 10
+print(f"device copy 2 GiB   {ms:8.3f} ms  {2 * (2 << 30) / ms / 1e6:7.0f} GB/s read+write  ({2 * (2 << 30) / ms / 1e6 / 8000:.2f} of the 8 TB/s peak)", flush=True)
