@@ -78,6 +78,13 @@ K32(and_or_b32,   "v_and_or_b32 %0, %0, %1, %1")
 K32(add_lshl_u32, "v_add_lshl_u32 %0, %0, %1, 1")
 K32(perm_b32,     "v_perm_b32 %0, %0, %1, %1")
 K32(mul_lo_sgpr,  "v_mul_lo_u32 %0, s4, %0")
+K32(and_sgpr,     "v_and_b32 %0, s4, %0")
+K32(and_literal,  "v_and_b32 %0, 0x0fffffff, %0")
+K32(lshr_sgpr,    "v_lshrrev_b32 %0, s4, %0")
+K32(lshr_28,      "v_lshrrev_b32 %0, 28, %0")
+K32(sub_sgpr,     "v_sub_u32 %0, s4, %0")
+K32(mov_sgpr,     "v_mov_b32 %0, s4")
+K32(xor_inline,   "v_xor_b32 %0, 8, %0")
 K32(sub_co_subb,  "v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %0, vcc, %0, %1, vcc")
 K32(pk_fma_f32_half, "v_fma_f32 %0, %0, %1, %1")
 K32(mad_u32_u24_v3,  "v_mad_u32_u24 %0, %0, %1, %1")
@@ -151,6 +158,9 @@ int main() {
     {"v_pk_fma_f32", k_pk_fma_f32, 1}, {"v_pk_add_f32", k_pk_add_f32, 1},
     {"v_mad_u64_u32 sgpr", k_mad_u64_sgpr, 1}, {"v_mad_u64_u32 +0", k_mad_u64_c0, 1},
     {"v_mov_b32_dpp", k_dpp_mov, 1}, {"v_add_u32_dpp row_ror", k_dpp_add, 1},
+    {"v_and_b32 sgpr src", k_and_sgpr, 1}, {"v_and_b32 literal", k_and_literal, 1},
+    {"v_lshrrev_b32 sgpr shift", k_lshr_sgpr, 1}, {"v_lshrrev_b32 inline 28", k_lshr_28, 1},
+    {"v_sub_u32 sgpr src", k_sub_sgpr, 1}, {"v_mov_b32 sgpr src", k_mov_sgpr, 1}, {"v_xor_b32 inline 8", k_xor_inline, 1},
     {"ds_bpermute_b32+wait", k_bpermute, 1}, {"ds_swizzle_b32+wait", k_swizzle, 1},
   };
   const int max_blocks = cus * 8 * 4;
