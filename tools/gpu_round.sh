@@ -12,5 +12,5 @@ timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "ben
 cat $OUT/bench.json
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r cat | head -12
