@@ -313,7 +313,25 @@ static tn_status host_pipe_init(tn_plan* p) {
 
 // launch(in0, in1, out, rows): enqueue the kernel for one chunk on p->stream (device pointers)
 template <typename Launch>
+static tn_status host_pipeline_run(tn_plan* p, int n_in, const void* const* in, void* out, size_t batch, Launch&& launch);
+
+// Never returns with copies or kernels still in flight on the caller's buffers: on an error the three streams
+// are drained before the status is handed back.
+template <typename Launch>
 static tn_status host_pipeline(tn_plan* p, int n_in, const void* const* in, void* out, size_t batch, Launch&& launch) {
+  const tn_status st = host_pipeline_run(p, n_in, in, out, batch, launch);
+  if (st != TN_OK) {
+    const std::string msg = g_err;                   // keep the first error's message
+    if (p->copy_in) (void)hipStreamSynchronize(p->copy_in);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->copy_out) (void)hipStreamSynchronize(p->copy_out);
+    g_err = msg;
+  }
+  return st;
+}
+
+template <typename Launch>
+static tn_status host_pipeline_run(tn_plan* p, int n_in, const void* const* in, void* out, size_t batch, Launch&& launch) {
   tn_status st;
   if ((st = host_pipe_init(p))) return st;
   const size_t row_bytes = (size_t)p->n * (size_t)p->elem_bytes;
