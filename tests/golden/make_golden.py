@@ -28,6 +28,11 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, os.path.join(REF, "new_reference"))
 import cg_ntt as ref          # noqa: E402
 import cg_ntt_8butterfly as ref8   # noqa: E402
+# second, independent reference model of the UNTWISTED transforms (the RTL testbench's golden model):
+# test/refs/ntt_forward_reference.py:38, ntt_inverse_reference.py:9 — parameters are passed per call
+sys.path.insert(0, os.path.join(REF, "test"))
+from refs.ntt_forward_reference import ntt_forward_reference as rtl_fwd    # noqa: E402
+from refs.ntt_inverse_reference import ntt_inverse_reference as rtl_inv    # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -72,7 +77,8 @@ def gen(tag):
     n, q, psi = PARAMS[tag]
     set_params(n, q)
     omega = pow(psi, 2, q)
-    arrays, meta = {}, {"n": n, "q": q, "psi": psi, "omega": omega, "cases": []}
+    arrays, meta = {}, {"n": n, "q": q, "psi": psi, "omega": omega, "cases": [],
+                        "cross_checked_with": ["new_reference/cg_ntt_8butterfly.py", "test/refs/ntt_forward_reference.py", "test/refs/ntt_inverse_reference.py"]}
 
     def poly_case(name, a, b):
         c = ref.nwc_poly_mult(list(a), list(b), psi)
@@ -88,6 +94,7 @@ def gen(tag):
         assert A == A8 and stages == stages8
         back = ref.cg_intt(list(A), omega, q)
         assert back == [x % q for x in a]
+        assert rtl_fwd(list(a), N=n, q=q, psi=psi) == A and rtl_inv(list(A), N=n, q=q, psi=psi) == back   # second oracle agrees
         assert ref8.cg_intt_8butterfly(list(A), omega, q) == back
         arrays[name + "_x"], arrays[name + "_X"] = u64(a), u64(A)
         w = min(16, n)
