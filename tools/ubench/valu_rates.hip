@@ -12,7 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
+#include <cstddef>
 #include <vector>
 #include <algorithm>
 
@@ -128,10 +130,33 @@ __global__ void k_clock(uint64_t* o) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { o[0] = c1 - c0; o[1] = r1 - r0; o[2] = x; }
 }
 
+// LDS traffic: each lane writes and reads back 8 bytes (a wave moves 512 B per instruction), 8 independent slots
+__global__ void __launch_bounds__(256) k_lds_rw64(uint32_t* out, uint64_t* cyc, uint32_t seed) {
+  __shared__ uint64_t buf[256 * 8];
+  uint64_t r[8];
+  for (int i = 0; i < 8; ++i) r[i] = (uint64_t)(seed + threadIdx.x * 8 + i) * 0x9E3779B97F4A7C15ull;
+  buf[threadIdx.x] = r[0];
+  __syncthreads();
+  const uint32_t base = (uint32_t)(uintptr_t)(&buf[0]) + threadIdx.x * 8u;
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER; ++it) {
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)
+      asm volatile("ds_write_b64 %1, %0 offset:%2\n\tds_read_b64 %0, %1 offset:%2" : "+v"(r[i]) : "v"(base), "n"(i * 2048) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= (uint32_t)r[i] ^ (uint32_t)(r[i] >> 32);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
 typedef void (*kern_t)(uint32_t*, uint64_t*, uint32_t);
 struct Entry { const char* name; kern_t k; int instr_per_slot; };
 
-int main() {
+// usage: valu_rates                      -> the issue-rate table
+//        valu_rates spin "<name>" secs flag -> run that one instruction back to back for `secs` seconds (creates `flag`
+//                                             while running) so rocm-smi can sample clock and power: energy per instruction
+int main(int argc, char** argv) {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
   printf("device=%s cus=%d clock_khz=%d\n", prop.name, cus, prop.clockRate);
@@ -161,6 +186,7 @@ int main() {
     {"v_and_b32 sgpr src", k_and_sgpr, 1}, {"v_and_b32 literal", k_and_literal, 1},
     {"v_lshrrev_b32 sgpr shift", k_lshr_sgpr, 1}, {"v_lshrrev_b32 inline 28", k_lshr_28, 1},
     {"v_sub_u32 sgpr src", k_sub_sgpr, 1}, {"v_mov_b32 sgpr src", k_mov_sgpr, 1}, {"v_xor_b32 inline 8", k_xor_inline, 1},
+    {"ds_write_b64+ds_read_b64", k_lds_rw64, 2},
     {"ds_bpermute_b32+wait", k_bpermute, 1}, {"ds_swizzle_b32+wait", k_swizzle, 1},
   };
   const int max_blocks = cus * 8 * 4;
@@ -168,6 +194,26 @@ int main() {
   CHECK(hipMalloc(&out, sizeof(uint32_t) * max_blocks * 256));
   CHECK(hipMalloc(&cyc, sizeof(uint64_t) * max_blocks * 4));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  if (argc >= 5 && !strcmp(argv[1], "spin")) {
+    const Entry* sel = nullptr;
+    for (auto& e : es) if (!strcmp(e.name, argv[2])) sel = &e;
+    if (!sel) { fprintf(stderr, "unknown instruction %s\n", argv[2]); return 2; }
+    const double secs = atof(argv[3]);
+    sel->k<<<max_blocks, 256>>>(out, cyc, 12345u); CHECK(hipDeviceSynchronize());
+    FILE* f = fopen(argv[4], "w"); if (f) { fputs("go\n", f); fclose(f); }
+    double total_ms = 0; long launches = 0;
+    while (total_ms < secs * 1e3) {
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < 20; ++i) sel->k<<<max_blocks, 256>>>(out, cyc, 12345u);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      total_ms += ms; launches += 20;
+    }
+    remove(argv[4]);
+    const double rate = (double)launches * max_blocks * 256 * ITER * 8 * sel->instr_per_slot / (total_ms * 1e-3);
+    printf("spin %-28s %.2f Tlane-op/s  %.3f G wave-instr/s\n", sel->name, rate / 1e12, rate / 64e9);
+    return 0;
+  }
   // effective clock under an all-CU VALU load: d(s_memtime)/d(s_memrealtime) * 100 MHz
   k_clock<<<cus * 8, 256>>>(cyc); CHECK(hipDeviceSynchronize());
   k_clock<<<cus * 8, 256>>>(cyc); CHECK(hipDeviceSynchronize());
