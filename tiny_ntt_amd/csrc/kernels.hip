@@ -1,10 +1,14 @@
 // kernels.hip — gfx950 kernels of libtinyntt and their launchers.
 //
-//  polymul_fused_kernel : K6, the throughput path.  One workgroup per polynomial
-//      pair; coefficients live in VGPRs (2^LPT per thread), the log2(n) radix-2
-//      stages run as ceil(log2 n / LPT) register phases with padded LDS
-//      transposes between them; psi-twist and n^-1 folded into the twiddles
-//      (fused_core.h).  HBM traffic per product = read a, read b, write c.
+//  polymul_fused_kernel : K6, the throughput path.  Persistent workgroups, one
+//      polynomial pair at a time; coefficients live in VGPRs (2^LPT per thread), the
+//      log2(n) radix-2 stages run as ceil(log2 n / LPT) register phases with LDS
+//      transposes between them (XOR-swizzled at n = 4096 / 64-bit lanes, padded
+//      otherwise); psi-twist and n^-1 folded into the twiddles (fused_core.h); the
+//      same kernel on the x^n - 1 twiddle tables is the cyclic product.
+//      HBM traffic per product = read a, read b, write c.
+//  ntt_fused_kernel     : the standalone transforms (twist+forward, cg_ntt, cg_intt)
+//      on the same machinery, natural order in and out.
 //  cg_kernel            : K1-K5/K7, the reference's own constant-geometry
 //      dataflow (cg_ntt.py:49-64) held in LDS ping-pong buffers, canonical
 //      arithmetic at every step so each stage's output equals the reference's
