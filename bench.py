@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--variant", default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scatter-gather", type=int, default=0, metavar="ROWS",
+                    help="N>1 only, off by default: also time the OPTIONAL scatter of a, b from rank 0 and gather of c "
+                         "(tiny_ntt_amd.dist, point-to-point over RCCL/xGMI) on ROWS rows per rank; reported separately, never part of value")
     args = ap.parse_args()
 
     import torch
@@ -205,6 +208,38 @@ def main():
     kernel_ms = tdist.max_over_ranks(kernel_ms, red_dev)
     achieved = rows * BYTES_PER_PRODUCT / (kernel_ms * 1e-3) / 1e9
 
+    sg = None
+    if args.scatter_gather > 0 and world > 1:
+        # optional data-movement leg: the compute path above never needs it
+        r_sg = min(args.scatter_gather, rows)
+        stage = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
+        back = (lambda t: t) if backend == "nccl" else (lambda t: t.to(dev))
+        full_a = stage(plan.fill_lcg(r_sg * world, 1, 2)) if rank == 0 else None
+        full_b = stage(plan.fill_lcg(r_sg * world, 2, 2)) if rank == 0 else None
+        sdev = dev if backend == "nccl" else torch.device("cpu")
+        barrier()
+        t1 = time.perf_counter()
+        my_a = tdist.scatter_rows(full_a, r_sg * world, N_COEFF, a.dtype, sdev)
+        my_b = tdist.scatter_rows(full_b, r_sg * world, N_COEFF, a.dtype, sdev)
+        torch.cuda.synchronize(dev); barrier()
+        t_sc = tdist.max_over_ranks(time.perf_counter() - t1, red_dev)
+        my_c = plan.poly_mult(back(my_a), back(my_b), variant=args.variant)
+        plan.synchronize()
+        t2 = time.perf_counter()
+        full_c = tdist.gather_rows(stage(my_c), r_sg * world, N_COEFF)
+        torch.cuda.synchronize(dev); barrier()
+        t_ga = tdist.max_over_ranks(time.perf_counter() - t2, red_dev)
+        ok = True
+        if rank == 0:
+            ref_c = plan.poly_mult(back(full_a), back(full_b), variant=args.variant)
+            plan.synchronize()
+            ok = bool(torch.equal(back(full_c), ref_c))
+        row_bytes = N_COEFF * 8
+        sg = {"rows_per_rank": r_sg, "scatter_ms": round(t_sc * 1e3, 3), "gather_ms": round(t_ga * 1e3, 3),
+              "scatter_GBps": round(2 * r_sg * (world - 1) * row_bytes / t_sc / 1e9, 1),
+              "gather_GBps": round(r_sg * (world - 1) * row_bytes / t_ga / 1e9, 1), "gathered_product_bit_exact": ok,
+              "transport": "RCCL point-to-point" if backend == "nccl" else "gloo (host staging)"}
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")   # HBM bytes per launch from separate rocprofv3 --pmc passes
     if os.path.exists(tpath):
@@ -249,6 +284,8 @@ def main():
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_PRODUCT},
             "cpu_baseline": base,
         }
+        if sg is not None:
+            line["scatter_gather"] = sg
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
