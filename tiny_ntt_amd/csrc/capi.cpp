@@ -125,6 +125,8 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, q, elem_bytes, &p->d_psi_inv_pow);
   if (e == hipSuccess) e = upload_tw(t.cyc_brv, q, elem_bytes, &p->d_cyc_brv);
   if (e == hipSuccess) e = upload_tw(t.cyc_inv_brv, q, elem_bytes, &p->d_cyc_inv_brv);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_sched, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
+  if (e == hipSuccess) e = hipMemset(p->d_sched, 0, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -136,7 +138,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
 extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   if (!p) return TN_OK;
   DeviceGuard guard(p->device);
-  void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_psi_inv_pow, p->d_cyc_brv, p->d_cyc_inv_brv, p->d_scratch};
+  void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_psi_inv_pow, p->d_cyc_brv, p->d_cyc_inv_brv, p->d_scratch, p->d_sched};
   for (void* t : tabs) if (t) (void)hipFree(t);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);

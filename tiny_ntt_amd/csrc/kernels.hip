@@ -53,6 +53,10 @@
 #ifndef TN_EX_LOOSE
 #define TN_EX_LOOSE 0            // 1: wave-local transposes without the outer scheduling fences (measured 1 % slower on MI355X)
 #endif
+#ifndef TN_DYNAMIC_ROWS
+#define TN_DYNAMIC_ROWS 1        // 1: persistent workgroups take their next row from a device counter (atomicAdd) instead of a fixed
+                                 //    stride: workgroups do not all run at the same speed, and with a fixed share the slowest sets the time
+#endif
 #ifdef TN_MARKS
 #define TN_MARK(n) asm volatile("; TNMARK " n)
 #else
@@ -194,7 +198,7 @@ template <typename E, int LOGN, int LPT, bool LAZY>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))   // 16 coeff/thread shapes need > 128 VGPRs
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
                      const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
-                     E* __restrict__ c, u32 batch) {
+                     E* __restrict__ c, u32 batch, u32* sched) {
   // The twiddle tables are separate __restrict__ kernel arguments (not fields of a struct) so the
   // compiler can prove the stores to c never alias them: wave-uniform twiddle loads then become
   // scalar loads (s_load_dwordx4) instead of vector loads that every wave would wait on.
@@ -207,12 +211,15 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // twiddles of the lane-dependent middle phases: staged once per (persistent) workgroup in LDS
   Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0));
   Tw* lds_inv = lds_fwd + Cfg::lds_tw_count();
+  u32* lds_next = reinterpret_cast<u32*>(lds_inv + Cfg::lds_tw_count());      // row index this workgroup takes next
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) {
     lds_fwd[i] = tab_fwd[Cfg::lds_tw_lo() + i];
     lds_inv[i] = tab_inv[Cfg::lds_tw_lo() + i];
   }
   __syncthreads();
-  // Persistent workgroup: rows blockIdx.x, blockIdx.x + gridDim.x, ...  The next row's first
+  // Persistent workgroup.  Rows: blockIdx.x first, then whatever the device-wide counter sched[0] hands out
+  // (gridDim.x + atomicAdd): a workgroup on a slower CU / XCD simply takes fewer rows, so the launch ends when the
+  // work does, not when the slowest fixed share does.  sched == nullptr: fixed stride gridDim.x.  The next row's first
   // operand is fetched from HBM into the registers that held b (dead after the pointwise
   // product) while the inverse transform of the current row runs; b itself is requested at the
   // top of the row and not needed until a's forward transform is done.
@@ -234,7 +241,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   bool have_c = false;
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) xa[r] = 0;
-  for (; row < batch; row += gridDim.x) {
+  while (row < batch) {
+    // one thread asks for the next row now; everyone reads the answer after a's transform (barriers in between)
+    if (tau == 0) *lds_next = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : row + gridDim.x;
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
     TN_MARK("loop_top");
@@ -259,6 +268,8 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
     for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
 #endif
+    __syncthreads();
+    const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
     forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
     // the inverse starts with the thread-private phase: request its twiddles before the product
@@ -271,7 +282,6 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     TN_MARK("pointwise");
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     TN_MARK("after_pointwise");
-    const u32 next = row + gridDim.x;
     const TwRefs<E> twi = {tab_inv, lds_inv, pre};
     inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {
       if (next < batch) {              // next row's first operand -> the registers that held b
@@ -285,8 +295,11 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #else
     st_result<E, Cfg>(c, row, tau, xa);
 #endif
+    row = next;
   }
   if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
+  // the last workgroup to run out of rows re-arms the counters for the next launch that uses this slot
+  if (sched && tau == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
 }
 
 // Standalone transforms on the register-tiled machinery, natural order in and out:
@@ -433,7 +446,7 @@ template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0)) * sizeof(E) +
-                           (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type);
+                           (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type) + 16;      // + the next-row slot
   auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -450,8 +463,11 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   // tables of the x^n - 1 factorisation tree (HostTables::cyc_brv), whose inverse table has entry 1 equal to 1
   Arith<E> ar = pv.ar;
   if (cyclic) ar.ninv_w1 = ar.ninv;
+  // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
+  u32* sched = nullptr;
+  if (TN_DYNAMIC_ROWS && p->d_sched) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
-                     cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch);
+                     cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched);
   return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <atomic>
 #include "fused_core.h"
 
 struct tn_plan {
@@ -35,6 +36,11 @@ struct tn_plan {
   void* d_cyc_brv = nullptr;       // [n]   merged twiddles of the cyclic transform (HostTables::cyc_brv): fused cg_ntt
   void* d_cyc_inv_brv = nullptr;   // [n]   their inverses: fused cg_intt
   void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
+  // dynamic row scheduling of the persistent fused kernel: SCHED_SLOTS pairs {next row, finished workgroups}, zeroed at
+  // plan creation and re-armed by the kernel itself; consecutive launches take consecutive slots
+  static constexpr unsigned SCHED_SLOTS = 256;
+  tn::u32* d_sched = nullptr;
+  mutable std::atomic<unsigned> sched_seq{0};
   void* d_scratch = nullptr;       // host-entry staging (grown on demand)
   size_t scratch_bytes = 0;
 };
