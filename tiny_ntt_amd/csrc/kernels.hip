@@ -57,12 +57,26 @@
 #define TN_DYNAMIC_ROWS 1        // 1: persistent workgroups take their next row from a device counter (atomicAdd) instead of a fixed
                                  //    stride: workgroups do not all run at the same speed, and with a fixed share the slowest sets the time
 #endif
+#ifndef TN_SCHED_CHUNK_BYTES
+#define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
+#endif
 #ifdef TN_MARKS
 #define TN_MARK(n) asm volatile("; TNMARK " n)
 #else
 #define TN_MARK(n)
 #endif
 namespace tn {
+
+// Rows handed out per atomicAdd of the dynamic row scheduler: TN_SCHED_CHUNK_BYTES worth of rows (2 at n = 4096 with
+// 64-bit lanes, 64 at n = 256 with 32-bit lanes) so the one counter address never becomes the bottleneck (one row per
+// atomic at n = 256 ran 13x slower than a fixed stride), but never so many that a small batch yields fewer than four
+// chunks per resident workgroup.
+static inline u32 sched_chunk_rows(size_t row_bytes, size_t batch, size_t resident) {
+  size_t c = (size_t)TN_SCHED_CHUNK_BYTES / row_bytes;
+  const size_t cap = batch / (4 * resident);
+  if (c > cap) c = cap;
+  return (u32)(c < 1 ? 1 : c);
+}
 
 // ============================================================================
 // Fused kernel
@@ -198,7 +212,7 @@ template <typename E, int LOGN, int LPT, bool LAZY>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))   // 16 coeff/thread shapes need > 128 VGPRs
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
                      const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
-                     E* __restrict__ c, u32 batch, u32* sched) {
+                     E* __restrict__ c, u32 batch, u32* sched, u32 chunk) {
   // The twiddle tables are separate __restrict__ kernel arguments (not fields of a struct) so the
   // compiler can prove the stores to c never alias them: wave-uniform twiddle loads then become
   // scalar loads (s_load_dwordx4) instead of vector loads that every wave would wait on.
@@ -217,15 +231,18 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     lds_inv[i] = tab_inv[Cfg::lds_tw_lo() + i];
   }
   __syncthreads();
-  // Persistent workgroup.  Rows: blockIdx.x first, then whatever the device-wide counter sched[0] hands out
-  // (gridDim.x + atomicAdd): a workgroup on a slower CU / XCD simply takes fewer rows, so the launch ends when the
-  // work does, not when the slowest fixed share does.  sched == nullptr: fixed stride gridDim.x.  The next row's first
+  // Persistent workgroup.  Rows come in chunks of `chunk` consecutive rows: chunk blockIdx.x first, then whatever the
+  // device-wide counter sched[0] hands out (atomicAdd): a workgroup on a slower CU / XCD simply takes fewer chunks, so
+  // the launch ends when the work does, not when the slowest fixed share does.  (chunk > 1 for short rows keeps the
+  // rate of atomics on that one address low.)  sched == nullptr: fixed stride.  The next row's first
   // operand is fetched from HBM into the registers that held b (dead after the pointwise
   // product) while the inverse transform of the current row runs; b itself is requested at the
   // top of the row and not needed until a's forward transform is done.
   E xa[Cfg::R], xb[Cfg::R];
   const Tw w_stage0 = tab_fwd[1];          // forward stage 0 uses this one twiddle in every row: resident in SGPRs
-  u32 row = blockIdx.x;
+  u32 row = blockIdx.x * chunk;
+  u32 left = chunk - 1;                     // rows still to take from the current chunk (thread 0's copy is the one used)
+  u32 chunk_id = blockIdx.x;
   if (row < batch) {
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, row, tau, r);
@@ -242,8 +259,15 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) xa[r] = 0;
   while (row < batch) {
-    // one thread asks for the next row now; everyone reads the answer after a's transform (barriers in between)
-    if (tau == 0) *lds_next = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : row + gridDim.x;
+    // one thread determines the next row now; everyone reads the answer after a's transform (barriers in between)
+    if (tau == 0) {
+      if (left) { --left; *lds_next = row + 1; }
+      else {
+        chunk_id = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id + gridDim.x;
+        left = chunk - 1;
+        *lds_next = chunk_id * chunk;
+      }
+    }
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
     TN_MARK("loop_top");
@@ -312,7 +336,8 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 // one extra LDS transpose through a natural-order image turns that into unit-stride HBM accesses.
 template <typename E, int LOGN, int LPT, bool LAZY, int MODE>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))
-ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab, const E* __restrict__ in, E* __restrict__ out, u32 batch) {
+ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab, const E* __restrict__ in, E* __restrict__ out, u32 batch,
+                 u32* sched, u32 chunk) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
@@ -320,19 +345,34 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
   E* lds = reinterpret_cast<E*>(tn_smem);
   const u32 tau = threadIdx.x;
   Tw* lds_tab = reinterpret_cast<Tw*>(lds + Cfg::lds_elems());
+  u32* lds_next = reinterpret_cast<u32*>(lds_tab + Cfg::lds_tw_count());
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) lds_tab[i] = tab[Cfg::lds_tw_lo() + i];
+  // rows: blockIdx.x, then whatever the device-wide counter hands out (see polymul_fused_kernel); the prefetch needs the
+  // next row at the top of an iteration, so the counter is asked one iteration ahead
+  u32 left = chunk - 1, chunk_id = blockIdx.x;            // thread 0's copies are the ones used
+  auto take_next = [&](u32 cur) {                         // thread 0 only
+    if (left) { --left; *lds_next = cur + 1; }
+    else {
+      chunk_id = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id + gridDim.x;
+      left = chunk - 1;
+      *lds_next = chunk_id * chunk;
+    }
+  };
+  if (tau == 0) take_next(blockIdx.x * chunk);
   __syncthreads();
+  u32 next = wave_uniform(*lds_next);
   constexpr int LAST = Cfg::PHASES - 1;
   // The next row's input is requested as soon as the current one has been consumed, so the HBM latency of row k+1
   // hides behind the arithmetic of row k (persistent workgroup, like the product kernel).
   E xn[Cfg::R];
-  u32 row = blockIdx.x;
+  u32 row = blockIdx.x * chunk;
   if (row < batch) {
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, row, tau, r);
   }
-  for (; row < batch; row += gridDim.x) {
-    const u32 next = row + gridDim.x;
+  while (row < batch) {
+    __syncthreads();                                     // everyone has read the previous answer
+    if (tau == 0) take_next(next);
     E x[Cfg::R];
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) x[r] = xn[r];
@@ -380,14 +420,17 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
       st_result<E, Cfg>(out, row, tau, x);
     }
     __syncthreads();
+    row = next;
+    next = wave_uniform(*lds_next);
   }
+  if (sched && tau == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
 }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef typename TwOf<E>::type Tw;
-  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw);
+  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw) + 16;   // + the next-row slot
   const PlanView<E> pv = make_view<E>(p);
   const void* kern = nullptr;
   const Tw* tab = nullptr;
@@ -403,9 +446,13 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
-  const u32 grid = (u32)(batch < resident ? batch : resident);
+  u32 chunk = sched_chunk_rows(Cfg::N * sizeof(E), batch, resident);
+  const size_t chunks = (batch + chunk - 1) / chunk;
+  const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
-  void* args[] = {&ar, &tab, &in_, &out_, &b32};
+  u32* sched = nullptr;               // dynamic hand-out only pays when every workgroup takes several chunks
+  if (TN_DYNAMIC_ROWS && p->d_sched && chunks >= 4 * resident) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
+  void* args[] = {&ar, &tab, &in_, &out_, &b32, &sched, &chunk};
   return hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
 }
 
@@ -457,17 +504,19 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
-  const u32 grid = (u32)(batch < resident ? batch : resident);
+  const u32 chunk = sched_chunk_rows(Cfg::N * sizeof(E), batch, resident);
+  const size_t chunks = (batch + chunk - 1) / chunk;
+  const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const PlanView<E> pv = make_view<E>(p);
   // cyclic = product in Z_q[x]/(x^n - 1) (python_poly_mult, test_ntt_poly_mult.py:38-43): same kernel, twiddle
   // tables of the x^n - 1 factorisation tree (HostTables::cyc_brv), whose inverse table has entry 1 equal to 1
   Arith<E> ar = pv.ar;
   if (cyclic) ar.ninv_w1 = ar.ninv;
   // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
-  u32* sched = nullptr;
-  if (TN_DYNAMIC_ROWS && p->d_sched) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
+  u32* sched = nullptr;               // (only pays when every workgroup takes several chunks; a short launch keeps the fixed stride)
+  if (TN_DYNAMIC_ROWS && p->d_sched && chunks >= 4 * resident) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
-                     cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched);
+                     cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched, chunk);
   return hipGetLastError();
 }
 
