@@ -372,6 +372,35 @@ def test_device_buffers_streams_and_aliasing(eng):
     assert plan.kernel_name("fused") == "polymul_fused_kernel" and plan.kernel_name("cg8") == "cg_kernel"
 
 
+def test_concurrent_launches_of_one_plan_on_several_streams(eng):
+    """The dynamically scheduled persistent kernels take their rows from device counters: launches of ONE plan that are
+    in flight together (different streams) must use different counter pairs.  Long launches (dynamic) and short ones
+    (fixed stride) mixed, products and standalone transforms, results compared with the same calls issued one by one."""
+    import torch
+    plan = plan_for(eng, "P4096_60")
+    sizes = [9000, 4097, 12000, 300, 7000, 2048]
+    ins = [(plan.fill_lcg(B, 10 * i + 1, 2), plan.fill_lcg(B, 10 * i + 2, 2)) for i, B in enumerate(sizes)]
+    plan.synchronize(); torch.cuda.synchronize()
+    ref = [plan.poly_mult(a, b) for a, b in ins]
+    ref_t = [plan.ntt_forward(a, variant="fused") for a, _ in ins]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in sizes]
+    for rep in range(3):
+        outs, outs_t = [], []
+        for (a, b), st in zip(ins, streams):
+            outs.append(plan.poly_mult(a, b, stream=st))
+            outs_t.append(plan.ntt_forward(a, variant="fused", stream=st))
+        torch.cuda.synchronize()
+        for i in range(len(sizes)):
+            assert torch.equal(outs[i], ref[i]) and torch.equal(outs_t[i], ref_t[i]), (rep, i)
+    # and many back-to-back launches on one stream (the counter pairs re-arm themselves and wrap around the ring)
+    a, b = ins[0]
+    for _ in range(600):
+        c = plan.poly_mult(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(c, ref[0])
+
+
 def test_config4_total_batch_1M_rows_on_one_gpu_max_size(eng, oracle):
     """BASELINE configs[3]'s whole batch (2^20 pairs, 96 GiB for a, b, c) on a single 288 GB MI355X: the largest
     size in BASELINE.json; exercises > 4 GiB offsets and the persistent grid's tail.  Size-independent checks:
