@@ -38,7 +38,7 @@ struct tn_plan {
   void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
   // dynamic row scheduling of the persistent fused kernel: SCHED_SLOTS pairs {next row, finished workgroups}, zeroed at
   // plan creation and re-armed by the kernel itself; consecutive launches take consecutive slots
-  static constexpr unsigned SCHED_SLOTS = 256;
+  static constexpr unsigned SCHED_SLOTS = 4096;   // a slot is reused only 4096 launches later: long before that its launch has retired
   tn::u32* d_sched = nullptr;
   mutable std::atomic<unsigned> sched_seq{0};
   void* d_scratch = nullptr;       // host-entry staging (grown on demand)
