@@ -35,7 +35,8 @@
 #define TN_NT_STREAM 1           // 1: non-temporal loads/stores for the streamed operands a, b, c
 #endif
 #ifndef TN_PARK_LDS
-#define TN_PARK_LDS 1            // 1: A^ waits in LDS (not registers) while b is transformed
+#define TN_PARK_LDS 0            // 1: A^ always waits in LDS while b is transformed; 0: in registers wherever that does not spill
+                                 //    (2 % faster, 32 KiB less LDS; see fused_parks())
 #endif
 #ifndef TN_FUSED_PAIR
 #define TN_FUSED_PAIR 0          // 1: transform a and b phase by phase together (shared twiddle loads, more live registers)
@@ -66,6 +67,11 @@
 #define TN_MARK(n)
 #endif
 namespace tn {
+
+// Does the fused product kernel park A^ in LDS while b is transformed?  Not any more: since the fold / pointwise trims
+// every lazy kernel keeps it in registers without spilling (the canonical-policy 64-bit kernel at n = 4096 spills 44
+// bytes per lane either way).
+template <typename E, int LOGN, bool LAZY> constexpr bool fused_parks() { return TN_PARK_LDS != 0; }
 
 // Rows handed out per atomicAdd of the dynamic row scheduler: TN_SCHED_CHUNK_BYTES worth of rows (2 at n = 4096 with
 // 64-bit lanes, 64 at n = 256 with 32-bit lanes) so the one counter address never becomes the bottleneck (one row per
@@ -223,7 +229,8 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   typedef typename TwOf<E>::type Tw;
   const u32 tau = threadIdx.x;
   // twiddles of the lane-dependent middle phases: staged once per (persistent) workgroup in LDS
-  Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0));
+  constexpr bool PARK = fused_parks<E, LOGN, LAZY>();
+  Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (PARK ? Cfg::N : 0));
   Tw* lds_inv = lds_fwd + Cfg::lds_tw_count();
   u32* lds_next = reinterpret_cast<u32*>(lds_inv + Cfg::lds_tw_count());      // row index this workgroup takes next
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) {
@@ -285,13 +292,13 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
     forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
-#if TN_PARK_LDS
-    // park A^ in a thread-private LDS slot while b is transformed (frees R registers)
+    // (where registers are short) park A^ in a thread-private LDS slot while b is transformed (frees R registers)
     // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
     PairOf<E>* park = reinterpret_cast<PairOf<E>*>(lds + Cfg::lds_elems()) + tau;
+    if constexpr (PARK) {
 #pragma unroll
-    for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
-#endif
+      for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
+    }
     __syncthreads();
     const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
@@ -299,10 +306,10 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
     tw_prefetch<E, Cfg>(pre, tau, tab_inv);
-#if TN_PARK_LDS
+    if constexpr (PARK) {
 #pragma unroll
-    for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
-#endif
+      for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
+    }
     TN_MARK("pointwise");
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     TN_MARK("after_pointwise");
@@ -492,7 +499,7 @@ bool fused_supported(u32 logn, int) { return fused_lpt(logn) != 0; }
 template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
-  const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (TN_PARK_LDS ? Cfg::N : 0)) * sizeof(E) +
+  const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (fused_parks<E, LOGN, LAZY>() ? Cfg::N : 0)) * sizeof(E) +
                            (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type) + 16;      // + the next-row slot
   auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
   if (lds_bytes > 48 * 1024) {
