@@ -61,6 +61,9 @@
 #ifndef TN_SCHED_CHUNK_BYTES
 #define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
 #endif
+#ifndef TN_SHARE_LAST_TW
+#define TN_SHARE_LAST_TW 1       // 1: a and b run their last forward phase back to back on ONE fetch of its thread-private twiddles
+#endif
 #ifdef TN_MARKS
 #define TN_MARK(n) asm volatile("; TNMARK " n)
 #else
@@ -120,29 +123,30 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
   }
 }
 
-// Forward transform.  The thread-private twiddles of the last phase are requested from L2 one
-// stage early (into pre[], inside fwd_phase), so their latency hides behind that stage and the transpose.
-template <typename E, typename Cfg, typename Pol>
-__device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
-                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
-                                            const typename TwOf<E>::type* first = nullptr) {
-  // first: stage 0's only twiddle (table entry 1), if the caller keeps it resident in registers
-  typename TwOf<E>::type pre[Cfg::NPRE];
+// Forward transform, phases [P0, P1).  The thread-private twiddles of the last phase live in pre[]; with `fetch_pre` they
+// are requested from L2 just before the transpose that precedes that phase, so their latency hides behind it.
+// first: stage 0's only twiddle (table entry 1), if the caller keeps it resident in registers.
+template <typename E, typename Cfg, typename Pol, int P0, int P1>
+__device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
+                                              const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
+                                              const typename TwOf<E>::type* first, typename TwOf<E>::type (&pre)[Cfg::NPRE], bool fetch_pre) {
   const TwRefs<E> tw = {glob, lds_tw, pre};
   typename TwOf<E>::type cur[Cfg::R / 2];            // scalar twiddles of the stage about to run (see TN_TW_AHEAD)
-  if constexpr (tw_ahead<Cfg, 0>()) {
-    if (first) cur[0] = *first;
-    else tw_stage<E, Cfg, 0, Cfg::stage_begin(0)>(tw, tau, cur);
+  if constexpr (tw_ahead<Cfg, P0>()) {
+    if (P0 == 0 && first) cur[0] = *first;
+    else tw_stage<E, Cfg, P0, Cfg::stage_begin(P0)>(tw, tau, cur);
   }
-  static_for<0, Cfg::PHASES>([&](auto p_) {
+  static_for<P0, P1>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     TN_MARK("fwd_phase");
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
     TN_MARK("fwd_other");
     if constexpr (TN_PREFETCH_LAST == 2 && p == Cfg::PHASES - 2) {
-      sched_fence();                   // request the last phase's private twiddles; they fly during the transpose
-      tw_prefetch<E, Cfg>(pre, tau, glob);
-      sched_fence();
+      if (fetch_pre) {
+        sched_fence();                 // request the last phase's private twiddles; they fly during the transpose
+        tw_prefetch<E, Cfg>(pre, tau, glob);
+        sched_fence();
+      }
     }
     if constexpr (p + 1 < Cfg::PHASES) {
       if constexpr (tw_ahead<Cfg, (p + 1 < Cfg::PHASES ? p + 1 : p)>()) {     // next phase's first scalar twiddles fly during the transpose
@@ -152,6 +156,13 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
       exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
     }
   });
+}
+template <typename E, typename Cfg, typename Pol>
+__device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
+                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
+                                            const typename TwOf<E>::type* first = nullptr) {
+  typename TwOf<E>::type pre[Cfg::NPRE];
+  forward_range<E, Cfg, Pol, 0, Cfg::PHASES>(x, tau, glob, lds_tw, ar, lds, first, pre, true);
 }
 
 // Inverse transform.  `after_first` runs once the first phase (the one whose thread-private
@@ -291,7 +302,10 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     sched_fence();
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
-    forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
+    constexpr bool SHARE = TN_SHARE_LAST_TW && !PARK && Cfg::PHASES >= 2 && TN_PREFETCH_LAST == 2;
+    Tw prf[Cfg::NPRE];                       // last forward phase's thread-private twiddles, shared by a and b
+    if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
+    else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
     // (where registers are short) park A^ in a thread-private LDS slot while b is transformed (frees R registers)
     // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
     PairOf<E>* park = reinterpret_cast<PairOf<E>*>(lds + Cfg::lds_elems()) + tau;
@@ -302,7 +316,13 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     __syncthreads();
     const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
-    forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
+    if constexpr (SHARE) {
+      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, true);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+    } else {
+      forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
+    }
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
     tw_prefetch<E, Cfg>(pre, tau, tab_inv);
