@@ -374,29 +374,6 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
   fwd_phase<E, Cfg, Pol, PH>(x, tau, tw, ar, cur);
 }
 
-// The same forward phase on TWO polynomials at once (a and b of one product): every twiddle
-// is loaded once and used for both butterflies, and the two chains interleave.
-template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase_pair(E (&x)[Cfg::R], E (&y)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
-  typedef Sched<Pol, Cfg::LOGN> S;
-  const u32 thi = Cfg::thi(PH, tau);
-  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
-    if (S::fwd_fold(s)) {
-#pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) { x[r] = fold(x[r], ar.k, ar.fold_c); y[r] = fold(y[r], ar.k, ar.fold_c); }
-    }
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) {
-      if (r & (1 << bpos)) continue;
-      const typename TwOf<E>::type w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
-      Pol::ct(x[r], x[r | (1 << bpos)], w, ar);
-      Pol::ct(y[r], y[r | (1 << bpos)], w, ar);
-    }
-  });
-}
-
 // One inverse phase (stages of phase PH in reverse order).  cur[]: as in fwd_phase (first executed stage = stage_end - 1).
 template <typename E, typename Cfg, typename Pol, int PH>
 TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, typename TwOf<E>::type (&cur)[Cfg::R / 2]) {

@@ -38,9 +38,6 @@
 #define TN_PARK_LDS 0            // 1: A^ always waits in LDS while b is transformed; 0: in registers wherever that does not spill
                                  //    (2 % faster, 32 KiB less LDS; see fused_parks())
 #endif
-#ifndef TN_FUSED_PAIR
-#define TN_FUSED_PAIR 0          // 1: transform a and b phase by phase together (shared twiddle loads, more live registers)
-#endif
 #ifndef TN_FUSED_LPT10
 #define TN_FUSED_LPT10 3         // log2(coefficients per thread) for n = 1024 (8 per thread: 219 vs 188 M products/s at 24 bits)
 #endif
