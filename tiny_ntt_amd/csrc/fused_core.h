@@ -277,6 +277,7 @@ template <typename E> struct TwRefs {
   const Tw* __restrict__ glob;     // full table psi^brv(i) (or inverse) in global memory / L2
   const Tw* lds;                   // entries [lds_tw_lo, lds_tw_hi) of it, staged in LDS
   Tw* pre;                         // the calling thread's last-phase twiddles, in registers
+  const Tw* mid = nullptr;         // optional: the calling thread's twiddles of the LDS-sourced phase, already in registers
 };
 
 template <typename E, typename Cfg, int PH, int S_>
@@ -284,8 +285,26 @@ TN_HD typename TwOf<E>::type tw_get(const TwRefs<E>& t, u32 thi, int g) {
   constexpr int bpos = (Cfg::LOGN - 1 - S_) - Cfg::pos(PH);
   if (Cfg::tw_src(PH) == Cfg::TW_REGS) return t.pre[Cfg::pre_off(S_) + g];
   const u32 idx = (1u << S_) + (TN_ABL_UNIFORM_TW ? 0u : (thi << (Cfg::LPT - bpos - 1))) + (u32)g;
-  if (Cfg::tw_src(PH) == Cfg::TW_LDS) return t.lds[idx - Cfg::lds_tw_lo()];
+  if (Cfg::tw_src(PH) == Cfg::TW_LDS) {
+    if (t.mid) return t.mid[(1 << (S_ - Cfg::stage_begin(PH))) - 1 + g];      // stage i of a full phase has 2^i twiddles, starting at 2^i - 1
+    return t.lds[idx - Cfg::lds_tw_lo()];
+  }
   return t.glob[idx];
+}
+
+// The calling thread's twiddles of an LDS-sourced FULL phase PH (LPT stages: 1 + 2 + ... = R - 1 of them), read into
+// registers once so that two transforms can run that phase on one fetch.
+template <typename E, typename Cfg, int PH>
+TN_HD void tw_fetch_mid(typename TwOf<E>::type (&mid)[Cfg::R], u32 tau, const typename TwOf<E>::type* lds_tw) {
+  const u32 thi = Cfg::thi(PH, tau);
+  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    constexpr int cnt = Cfg::R >> (bpos + 1), off = (1 << (s - Cfg::stage_begin(PH))) - 1;
+#pragma unroll
+    for (int g = 0; g < cnt; ++g)
+      mid[off + g] = lds_tw[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g - Cfg::lds_tw_lo()];
+  });
 }
 
 // Phases whose twiddles are wave-uniform (scalar loads): they are requested one stage ahead (TN_TW_AHEAD).

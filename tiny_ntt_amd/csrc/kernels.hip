@@ -58,6 +58,9 @@
 #ifndef TN_SCHED_CHUNK_BYTES
 #define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
 #endif
+#ifndef TN_SHARE_MID_TW
+#define TN_SHARE_MID_TW 1        // 1: ... and the phase before it (twiddles staged in LDS) likewise: a: ph 0-1, b: ph 0-1, a: ph 2, b: ph 2, b: ph 3, a: ph 3
+#endif
 #ifndef TN_SHARE_LAST_TW
 #define TN_SHARE_LAST_TW 1       // 1: a and b run their last forward phase back to back on ONE fetch of its thread-private twiddles
 #endif
@@ -126,8 +129,9 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
 template <typename E, typename Cfg, typename Pol, int P0, int P1>
 __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
                                               const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
-                                              const typename TwOf<E>::type* first, typename TwOf<E>::type (&pre)[Cfg::NPRE], bool fetch_pre) {
-  const TwRefs<E> tw = {glob, lds_tw, pre};
+                                              const typename TwOf<E>::type* first, typename TwOf<E>::type (&pre)[Cfg::NPRE], bool fetch_pre,
+                                              const typename TwOf<E>::type* mid = nullptr) {
+  const TwRefs<E> tw = {glob, lds_tw, pre, mid};
   typename TwOf<E>::type cur[Cfg::R / 2];            // scalar twiddles of the stage about to run (see TN_TW_AHEAD)
   if constexpr (tw_ahead<Cfg, P0>()) {
     if (P0 == 0 && first) cur[0] = *first;
@@ -300,8 +304,13 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
     constexpr bool SHARE = TN_SHARE_LAST_TW && !PARK && Cfg::PHASES >= 2 && TN_PREFETCH_LAST == 2;
+    // SHARE2: the phase before the last is a full LDS-sourced phase: its 2^LPT - 1 twiddles are read into registers once
+    constexpr int PM = Cfg::PHASES >= 3 ? Cfg::PHASES - 2 : 0;
+    constexpr bool SHARE2 = SHARE && TN_SHARE_MID_TW && Cfg::PHASES >= 3 && Cfg::tw_src(PM) == Cfg::TW_LDS &&
+                            Cfg::stage_end(PM) - Cfg::stage_begin(PM) == Cfg::LPT;
     Tw prf[Cfg::NPRE];                       // last forward phase's thread-private twiddles, shared by a and b
-    if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
+    if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
+    else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
     else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
     // (where registers are short) park A^ in a thread-private LDS slot while b is transformed (frees R registers)
     // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
@@ -313,7 +322,15 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     __syncthreads();
     const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
-    if constexpr (SHARE) {
+    if constexpr (SHARE2) {
+      forward_range<E, Cfg, Pol, 0, PM>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
+      Tw mid[Cfg::R];
+      tw_fetch_mid<E, Cfg, PM>(mid, tau, lds_fwd);
+      forward_range<E, Cfg, Pol, PM, PM + 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false, mid);
+      forward_range<E, Cfg, Pol, PM, PM + 1>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, true, mid);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+    } else if constexpr (SHARE) {
       forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, true);
       forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
       forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
