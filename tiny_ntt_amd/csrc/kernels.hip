@@ -385,23 +385,27 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
   E* lds = reinterpret_cast<E*>(tn_smem);
   const u32 tau = threadIdx.x;
-  Tw* lds_tab = reinterpret_cast<Tw*>(lds + Cfg::lds_elems());
+  // LDS: [transpose image][natural-order image][staged twiddles][2 next-row slots].  The natural-order image has its own
+  // region so that the only workgroup barrier a row adds to those of the cross-wave transpose is the one between writing
+  // and reading that image; the next-row slot is double-buffered for the same reason.
+  E* nat = lds + Cfg::lds_elems();
+  Tw* lds_tab = reinterpret_cast<Tw*>(nat + Cfg::N);
   u32* lds_next = reinterpret_cast<u32*>(lds_tab + Cfg::lds_tw_count());
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) lds_tab[i] = tab[Cfg::lds_tw_lo() + i];
-  // rows: blockIdx.x, then whatever the device-wide counter hands out (see polymul_fused_kernel); the prefetch needs the
-  // next row at the top of an iteration, so the counter is asked one iteration ahead
+  // rows: chunk blockIdx.x, then whatever the device-wide counter hands out (see polymul_fused_kernel); the prefetch needs
+  // the next row at the top of an iteration, so the counter is asked one iteration ahead
   u32 left = chunk - 1, chunk_id = blockIdx.x;            // thread 0's copies are the ones used
-  auto take_next = [&](u32 cur) {                         // thread 0 only
-    if (left) { --left; *lds_next = cur + 1; }
+  auto take_next = [&](u32 cur, u32 slot) {               // thread 0 only
+    if (left) { --left; lds_next[slot] = cur + 1; }
     else {
       chunk_id = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id + gridDim.x;
       left = chunk - 1;
-      *lds_next = chunk_id * chunk;
+      lds_next[slot] = chunk_id * chunk;
     }
   };
-  if (tau == 0) take_next(blockIdx.x * chunk);
+  if (tau == 0) take_next(blockIdx.x * chunk, 1u);
   __syncthreads();
-  u32 next = wave_uniform(*lds_next);
+  u32 next = wave_uniform(lds_next[1]);
   constexpr int LAST = Cfg::PHASES - 1;
   // The next row's input is requested as soon as the current one has been consumed, so the HBM latency of row k+1
   // hides behind the arithmetic of row k (persistent workgroup, like the product kernel).
@@ -411,9 +415,8 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, row, tau, r);
   }
-  while (row < batch) {
-    __syncthreads();                                     // everyone has read the previous answer
-    if (tau == 0) take_next(next);
+  for (u32 it = 0; row < batch; ++it) {
+    if (tau == 0) take_next(next, it & 1u);              // read back after this row's barrier(s)
     E x[Cfg::R];
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) x[r] = xn[r];
@@ -427,10 +430,10 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) x[r] = Pol::load(x[r], ar);
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))] = x[r];
+      for (int r = 0; r < Cfg::R; ++r) nat[Cfg::nat_addr(Cfg::jidx(0, tau, r))] = x[r];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))];
+      for (int r = 0; r < Cfg::R; ++r) x[r] = nat[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))];
       Tw pre[Cfg::NPRE];
       tw_prefetch<E, Cfg>(pre, tau, tab);
       const TwRefs<E> tw = {tab, lds_tab, pre};
@@ -451,18 +454,17 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
         for (int r = Cfg::R / 2; r < Cfg::R; ++r) x[r] = Pol::load(x[r], ar);
       }
       forward_all<E, Cfg, Pol>(x, tau, tab, lds_tab, ar, lds);
-      __syncthreads();
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r)
-        lds[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[r], ar) : x[r];
+        nat[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[r], ar) : x[r];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
+      for (int r = 0; r < Cfg::R; ++r) x[r] = nat[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
       st_result<E, Cfg>(out, row, tau, x);
     }
-    __syncthreads();
+    if (Cfg::THREADS <= 64) __syncthreads();             // single-wave workgroups have no barrier inside the transposes
     row = next;
-    next = wave_uniform(*lds_next);
+    next = wave_uniform(lds_next[it & 1u]);
   }
   if (sched && tau == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
 }
@@ -471,7 +473,7 @@ template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   typedef typename TwOf<E>::type Tw;
-  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw) + 16;   // + the next-row slot
+  const size_t lds_bytes = (size_t)(Cfg::lds_elems() + Cfg::N) * sizeof(E) + (size_t)Cfg::lds_tw_count() * sizeof(Tw) + 16;   // + natural image, next-row slots
   const PlanView<E> pv = make_view<E>(p);
   const void* kern = nullptr;
   const Tw* tab = nullptr;
