@@ -20,9 +20,9 @@ int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, s
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
   Arith<E> ar = h_make_arith<E>(t);
-  if (cyclic) ar.ninv_w1 = ar.ninv;                        // as launch_fused_t: product in Z_q[x]/(x^n - 1)
-  const std::vector<Tw> psi_brv = h_tw_table<E>(cyclic ? t.cyc_brv : t.psi_brv, t.q),
-                        psi_inv_brv = h_tw_table<E>(cyclic ? t.cyc_inv_brv : t.psi_inv_brv, t.q);
+  if (cyclic) ar.fninv_w1 = ar.fninv;                      // as launch_fused_t: product in Z_q[x]/(x^n - 1)
+  const std::vector<Tw> psi_brv = h_fused_table<E>(cyclic ? t.cyc_brv : t.psi_brv, t),
+                        psi_inv_brv = h_fused_table<E>(cyclic ? t.cyc_inv_brv : t.psi_inv_brv, t);
   std::vector<E> lds(Cfg::lds_elems());
   struct Regs { E x[Cfg::R]; };
   std::vector<Regs> xa(Cfg::THREADS), xb(Cfg::THREADS);
@@ -91,8 +91,8 @@ int fused_ntt_emu(const HostTables& t, int mode, const u64* in, u64* out) {
   typedef Policy<E, LAZY> Pol;
   typedef typename TwOf<E>::type Tw;
   Arith<E> ar = h_make_arith<E>(t);
-  if (mode == 2) ar.ninv_w1 = ar.ninv;                      // cyc_inv_brv[1] = 1 (as launch_nttf_t does)
-  const std::vector<Tw> tab = h_tw_table<E>(mode == 2 ? t.cyc_inv_brv : (mode == 1 ? t.cyc_brv : t.psi_brv), t.q);
+  if (mode == 2) ar.fninv_w1 = ar.fninv;                    // cyc_inv_brv[1] = 1 (as launch_nttf_t does)
+  const std::vector<Tw> tab = h_fused_table<E>(mode == 2 ? t.cyc_inv_brv : (mode == 1 ? t.cyc_brv : t.psi_brv), t);
   std::vector<Tw> lds_tab(tab.begin() + Cfg::lds_tw_lo(), tab.begin() + Cfg::lds_tw_hi());
   std::vector<E> lds(Cfg::lds_elems());
   struct Regs { E x[Cfg::R]; };
@@ -137,11 +137,11 @@ int fused_ntt_emu(const HostTables& t, int mode, const u64* in, u64* out) {
 template <typename E, bool LAZY>
 int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
   switch (t.logn) {
-    case 8: return fused_ntt_emu<E, 8, 2, LAZY>(t, mode, in, out);
-    case 9: return fused_ntt_emu<E, 9, 3, LAZY>(t, mode, in, out);
-    case 10: return fused_ntt_emu<E, 10, 3, LAZY>(t, mode, in, out);
-    case 11: return fused_ntt_emu<E, 11, 3, LAZY>(t, mode, in, out);
-    case 12: return fused_ntt_emu<E, 12, 3, LAZY>(t, mode, in, out);
+    case 8: return fused_ntt_emu<E, 8, fused_lpt(8), LAZY>(t, mode, in, out);
+    case 9: return fused_ntt_emu<E, 9, fused_lpt(9), LAZY>(t, mode, in, out);
+    case 10: return fused_ntt_emu<E, 10, fused_lpt(10), LAZY>(t, mode, in, out);
+    case 11: return fused_ntt_emu<E, 11, fused_lpt(11), LAZY>(t, mode, in, out);
+    case 12: return fused_ntt_emu<E, 12, fused_lpt(12), LAZY>(t, mode, in, out);
     default: return 7;
   }
 }
@@ -149,11 +149,11 @@ int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
 template <typename E, bool LAZY>
 int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch, bool cyclic) {
   switch (t.logn) {
-    case 8: return fused_polymul_emu<E, 8, 2, LAZY>(t, a, b, c, batch, cyclic);
-    case 9: return fused_polymul_emu<E, 9, 3, LAZY>(t, a, b, c, batch, cyclic);
-    case 10: return fused_polymul_emu<E, 10, 3, LAZY>(t, a, b, c, batch, cyclic);
-    case 11: return fused_polymul_emu<E, 11, 3, LAZY>(t, a, b, c, batch, cyclic);
-    case 12: return fused_polymul_emu<E, 12, 3, LAZY>(t, a, b, c, batch, cyclic);
+    case 8: return fused_polymul_emu<E, 8, fused_lpt(8), LAZY>(t, a, b, c, batch, cyclic);
+    case 9: return fused_polymul_emu<E, 9, fused_lpt(9), LAZY>(t, a, b, c, batch, cyclic);
+    case 10: return fused_polymul_emu<E, 10, fused_lpt(10), LAZY>(t, a, b, c, batch, cyclic);
+    case 11: return fused_polymul_emu<E, 11, fused_lpt(11), LAZY>(t, a, b, c, batch, cyclic);
+    case 12: return fused_polymul_emu<E, 12, fused_lpt(12), LAZY>(t, a, b, c, batch, cyclic);
     default: return 7;
   }
 }
@@ -264,17 +264,17 @@ int emu_cg(uint32_t n, uint64_t q, uint64_t psi, int mode, const uint64_t* a, co
 // see cfg_probe() above for `what`
 long emu_cfg_probe(int logn, int elem_bytes, int what, unsigned a0, unsigned a1, unsigned a2) {
   if (elem_bytes == 8) {
-    if (logn == 8) return cfg_probe<u64, 8, 2>(what, a0, a1, a2);
-    if (logn == 9) return cfg_probe<u64, 9, 3>(what, a0, a1, a2);
-    if (logn == 10) return cfg_probe<u64, 10, 3>(what, a0, a1, a2);
-    if (logn == 11) return cfg_probe<u64, 11, 3>(what, a0, a1, a2);
-    if (logn == 12) return cfg_probe<u64, 12, 3>(what, a0, a1, a2);
+    if (logn == 8) return cfg_probe<u64, 8, fused_lpt(8)>(what, a0, a1, a2);
+    if (logn == 9) return cfg_probe<u64, 9, fused_lpt(9)>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u64, 10, fused_lpt(10)>(what, a0, a1, a2);
+    if (logn == 11) return cfg_probe<u64, 11, fused_lpt(11)>(what, a0, a1, a2);
+    if (logn == 12) return cfg_probe<u64, 12, fused_lpt(12)>(what, a0, a1, a2);
   } else {
-    if (logn == 8) return cfg_probe<u32, 8, 2>(what, a0, a1, a2);
-    if (logn == 9) return cfg_probe<u32, 9, 3>(what, a0, a1, a2);
-    if (logn == 10) return cfg_probe<u32, 10, 3>(what, a0, a1, a2);
-    if (logn == 11) return cfg_probe<u32, 11, 3>(what, a0, a1, a2);
-    if (logn == 12) return cfg_probe<u32, 12, 3>(what, a0, a1, a2);
+    if (logn == 8) return cfg_probe<u32, 8, fused_lpt(8)>(what, a0, a1, a2);
+    if (logn == 9) return cfg_probe<u32, 9, fused_lpt(9)>(what, a0, a1, a2);
+    if (logn == 10) return cfg_probe<u32, 10, fused_lpt(10)>(what, a0, a1, a2);
+    if (logn == 11) return cfg_probe<u32, 11, fused_lpt(11)>(what, a0, a1, a2);
+    if (logn == 12) return cfg_probe<u32, 12, fused_lpt(12)>(what, a0, a1, a2);
   }
   return -1;
 }
@@ -298,6 +298,30 @@ uint64_t emu_pointwise_lazy64(uint64_t a, uint64_t b, uint64_t q) {
   const int k = h_bitlen(q);
   Arith<u64> ar; ar.q = q; ar.k = k; ar.fold_c = (u32)((((u64)1) << k) - q); ar.mu = 0;
   return pointwise_lazy(a, b, ar);
+}
+// split-constant product (lazy 64-bit lanes): u + a*w as mul_sp_acc computes it; *ok = 0 if (k, c) is not admissible
+uint64_t emu_mul_sp_acc(uint64_t u, uint64_t a, uint64_t w, uint64_t q) {
+  const int k = h_bitlen(q), p = k - 31;
+  SplitK sk; sk.mulp = (u32)1 << p; sk.cf = (u32)((((unsigned __int128)1) << (p + 32)) % q);
+  return mul_sp_acc(u, a, h_make_tw64_split(w, q, k), sk);
+}
+int emu_split_sched_ok(uint32_t logn, uint64_t q) { const int k = h_bitlen(q); return h_split_sched_ok(logn, k, (((u64)1) << k) - q) ? 1 : 0; }
+// schedule statistics for one shape: what 0 folds in a forward transform per thread, 1 folds in an inverse, 2 forward output bound (units of 2^k/4096), 3 pw_fold_b
+long emu_split_sched_stat(int logn, int what) {
+  auto stat = [&](auto cfg) -> long {
+    typedef decltype(cfg) C; typedef SplitSched<C> S;
+    long f = 0, i = 0;
+    for (int s = 0; s < C::LOGN; ++s) for (int r = 0; r < C::R; ++r) { f += S::D.ffold[s][r]; i += S::D.ifold[s][r]; }
+    return what == 0 ? f : what == 1 ? i : what == 2 ? S::D.fout : (long)S::D.pw_fold_b;
+  };
+  switch (logn) {
+    case 8: return stat(FusedCfg<u64, 8, fused_lpt(8)>());
+    case 9: return stat(FusedCfg<u64, 9, fused_lpt(9)>());
+    case 10: return stat(FusedCfg<u64, 10, fused_lpt(10)>());
+    case 11: return stat(FusedCfg<u64, 11, fused_lpt(11)>());
+    case 12: return stat(FusedCfg<u64, 12, fused_lpt(12)>());
+  }
+  return -1;
 }
 uint32_t emu_fold32(uint32_t x, uint32_t q) { const int k = h_bitlen(q); return fold(x, k, (u32)((((u64)1) << k) - q)); }
 

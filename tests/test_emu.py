@@ -186,7 +186,8 @@ def test_fused_emulation_modulus_sweep(emu, oracle, n):
             X = emu.fused_ntt(n, q, psi, 1, a[1])
             assert np.array_equal(X, oracle.cg_ntt(a[1], psi * psi % q, q)), (n, q)
             assert np.array_equal(emu.fused_ntt(n, q, psi, 2, X), a[1] % np.uint64(q)), (n, q)
-    assert {26, 41, 47, 52, 57, 60} <= lazy and not ({61, 62} & lazy)
+    # 64-bit lanes: the split-constant product needs 2^33 c << 2^k (h_split_sched_ok), which no 41-bit NTT prime meets
+    assert {26, 47, 52, 57, 60} <= lazy and not ({61, 62} & lazy)
 
 
 @pytest.mark.parametrize("tag", ["P256", "P1024", "P4096", "P4096_60"])

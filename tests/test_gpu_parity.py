@@ -182,7 +182,8 @@ def test_modulus_sweep_every_word_size_both_policies(eng, oracle, n):
             assert np.array_equal(A[1], oracle.cg_ntt(a[1], plan.omega, q)), (n, q)
             assert np.array_equal(plan.ntt_inverse(A.astype(plan.dtype), variant="fused").astype(np.uint64), a % np.uint64(q)), (n, q)
             plan.close()
-    assert {26, 41, 47, 52, 57, 60} <= seen_lazy and {20, 31, 32, 33, 36, 61, 62} <= seen_canon, (seen_lazy, seen_canon)
+    # (64-bit lanes are lazy only when 2^33 c << 2^k, h_split_sched_ok: at n = 4096 no 41- or 47-bit NTT prime is that close to 2^k)
+    assert {26, 52, 57, 60} <= seen_lazy and {20, 31, 32, 33, 36, 41, 61, 62} <= seen_canon, (seen_lazy, seen_canon)
 
 
 def test_sizes_without_a_fused_kernel_use_cg(eng, oracle):

@@ -53,19 +53,13 @@ class Cfg:
     def accesses(self, ex, phase):
         """Wave instructions of a store/load of exchange `ex` in the register layout of `phase`:
         list of (width_bytes, [byte address per lane])."""
-        pos0 = self.p(7, phase) == 0
         out = []
         for wave in range(max(1, self.threads // 64)):
             lanes = [wave * 64 + l for l in range(min(64, self.threads))]
-            # threads that own contiguous coefficients use 16-byte accesses (pairs of u64 / quads of u32)
-            per = 16 // self.eb if pos0 else 1
-            for r in range(0, self.R, per):
-                addrs = [self.p(6, ex, self.p(5, phase, t, r)) * self.eb for t in lanes]
-                if per > 1:      # contiguity of the merged access
-                    for k in range(1, per):
-                        nxt = [self.p(6, ex, self.p(5, phase, t, r + k)) * self.eb for t in lanes]
-                        assert all(b == a + k * self.eb for a, b in zip(addrs, nxt))
-                out.append((16 if per > 1 else self.eb, addrs))
+            # element-wide accesses at base + immediate offset (the compiler pairs them into ds_{read,write}2_b64 /
+            # _b32, i.e. two independent element-wide accesses per lane: same banking per access)
+            for r in range(self.R):
+                out.append((self.eb, [self.p(6, ex, self.p(5, phase, t, r)) * self.eb for t in lanes]))
         return out
 
 
@@ -89,11 +83,24 @@ def worst_degrees(cfg):
 def test_bench_config_transposes_are_bank_conflict_free(probe):
     cfg = Cfg(probe, 12, 8)                        # n = 4096, 64-bit: the benchmark configuration
     assert (cfg.threads, cfg.R, cfg.phases) == (512, 8, 4)
-    assert cfg.lds == 4096                         # swizzled image: exactly one polynomial
+    assert cfg.lds == 4608                         # padded image: 8 wave regions of 512 + 64 elements
     for key, (w, r) in worst_degrees(cfg).items():
         assert (w, r) == (1, 1), f"exchange {key}: write {w}-way, read {r}-way"
     # exchanges 1 and 2 stay inside a wave (no workgroup barrier), exchange 0 does not
     assert [cfg.p(4, e) for e in range(3)] == [0, 1, 1]
+
+
+def test_layout_addresses_are_additive_in_the_register_index(probe):
+    """ex_store / ex_load address a coefficient as ex_base(thread) + ex_off(register) (one address register per side,
+    immediate offsets): that must equal the layout function for every thread and register of both sides."""
+    for logn, eb in ((12, 8), (12, 4), (11, 8), (11, 4), (10, 4), (10, 8), (9, 8), (9, 4), (8, 4), (8, 8)):
+        cfg = Cfg(probe, logn, eb)
+        for ex in range(cfg.phases - 1):
+            for phase in (ex, ex + 1):
+                off = [cfg.p(6, ex, cfg.p(5, phase, 0, r)) for r in range(cfg.R)]
+                for t in range(cfg.threads):
+                    base = cfg.p(6, ex, cfg.p(5, phase, t, 0))
+                    assert all(cfg.p(6, ex, cfg.p(5, phase, t, r)) == base + off[r] for r in range(cfg.R)), (logn, eb, ex, phase, t)
 
 
 def test_layouts_are_injective_and_wave_private_where_claimed(probe):

@@ -52,24 +52,18 @@ extern "C" const char* tn_status_string(tn_status s) {
   return "unknown";
 }
 
-// Upload a table of constants as Tw32[] or Tw64[] (value + Barrett quotient factor).
-static hipError_t upload_tw(const std::vector<u64>& vals, u64 q, int elem_bytes, void** dptr) {
+// Upload a table of constants as Tw32[] or Tw64[]: Shoup records (value + Barrett quotient factor), or for the
+// fused kernels' tables (fused = true) whatever h_make_fused_tw picks for this plan (split constants when lazy, 64-bit).
+static hipError_t upload_tw(const std::vector<u64>& vals, const HostTables& t, bool fused, void** dptr) {
   hipError_t e;
-  if (elem_bytes == 8) {
-    std::vector<Tw64> t(vals.size());
-    for (size_t i = 0; i < vals.size(); ++i) t[i] = h_make_tw64(vals[i], q);
-    if ((e = hipMalloc(dptr, t.size() * sizeof(Tw64))) != hipSuccess) return e;
-    return hipMemcpy(*dptr, t.data(), t.size() * sizeof(Tw64), hipMemcpyHostToDevice);
+  if (t.elem_bytes == 8) {
+    const std::vector<Tw64> r = fused ? h_fused_table<u64>(vals, t) : h_tw_table<u64>(vals, t.q);
+    if ((e = hipMalloc(dptr, r.size() * sizeof(Tw64))) != hipSuccess) return e;
+    return hipMemcpy(*dptr, r.data(), r.size() * sizeof(Tw64), hipMemcpyHostToDevice);
   }
-  std::vector<Tw32> t(vals.size());
-  for (size_t i = 0; i < vals.size(); ++i) t[i] = h_make_tw32(vals[i], q);
-  if ((e = hipMalloc(dptr, t.size() * sizeof(Tw32))) != hipSuccess) return e;
-  return hipMemcpy(*dptr, t.data(), t.size() * sizeof(Tw32), hipMemcpyHostToDevice);
-}
-
-static void set_tw(u64 w, u64 q, int elem_bytes, u64* ow, u64* owp) {
-  if (elem_bytes == 8) { Tw64 t = h_make_tw64(w, q); *ow = t.w; *owp = t.wp; }
-  else { Tw32 t = h_make_tw32(w, q); *ow = t.w; *owp = t.wp; }
+  const std::vector<Tw32> r = fused ? h_fused_table<u32>(vals, t) : h_tw_table<u32>(vals, t.q);
+  if ((e = hipMalloc(dptr, r.size() * sizeof(Tw32))) != hipSuccess) return e;
+  return hipMemcpy(*dptr, r.data(), r.size() * sizeof(Tw32), hipMemcpyHostToDevice);
 }
 
 extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags) {
@@ -105,26 +99,24 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   const HostTables t = h_build_tables(n, q, psi, !(flags & TN_PLAN_FORCE_CANONICAL));
   p->n = n; p->logn = logn; p->q = q; p->psi = psi; p->omega = t.omega;
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
-  p->k = t.k; p->mu = t.mu; p->lazy = t.lazy; p->fold_c = t.fold_c;
+  p->k = t.k; p->lazy = t.lazy;
+  if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
   p->has_fused = fused_supported(logn, elem_bytes);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount;
   }
-  set_tw(1, q, elem_bytes, &p->one_w, &p->one_wp);
-  set_tw(t.n_inv, q, elem_bytes, &p->ninv_w, &p->ninv_wp);
-  set_tw(t.ninv_w1, q, elem_bytes, &p->ninv_w1_w, &p->ninv_w1_wp);
 
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = upload_tw(t.psi_brv, q, elem_bytes, &p->d_psi_brv);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_brv, q, elem_bytes, &p->d_psi_inv_brv);
-  if (e == hipSuccess) e = upload_tw(t.omega_pow, q, elem_bytes, &p->d_omega_pow);
-  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, q, elem_bytes, &p->d_omega_inv_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_pow, q, elem_bytes, &p->d_psi_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, q, elem_bytes, &p->d_psi_inv_ninv);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, q, elem_bytes, &p->d_psi_inv_pow);
-  if (e == hipSuccess) e = upload_tw(t.cyc_brv, q, elem_bytes, &p->d_cyc_brv);
-  if (e == hipSuccess) e = upload_tw(t.cyc_inv_brv, q, elem_bytes, &p->d_cyc_inv_brv);
+  if (e == hipSuccess) e = upload_tw(t.psi_brv, t, true, &p->d_psi_brv);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_brv, t, true, &p->d_psi_inv_brv);
+  if (e == hipSuccess) e = upload_tw(t.omega_pow, t, false, &p->d_omega_pow);
+  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, false, &p->d_omega_inv_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_pow, t, false, &p->d_psi_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, t, false, &p->d_psi_inv_ninv);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, t, false, &p->d_psi_inv_pow);
+  if (e == hipSuccess) e = upload_tw(t.cyc_brv, t, true, &p->d_cyc_brv);
+  if (e == hipSuccess) e = upload_tw(t.cyc_inv_brv, t, true, &p->d_cyc_inv_brv);
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_sched, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
   if (e == hipSuccess) e = hipMemset(p->d_sched, 0, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
@@ -241,12 +233,16 @@ extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out)
   if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
   TN_ON_DEVICE(p);
-  // device records are {w, w'} pairs; only the constants w are exported, as uint64
+  // device records are {w, w'} pairs (or, tables 4 and 5 of a lazy 64-bit plan, split constants); only the
+  // constants w are exported, as uint64
   std::vector<unsigned char> raw(count * 2 * (size_t)p->elem_bytes);
   TN_HIP(hipMemcpy(raw.data(), tabs[which], raw.size(), hipMemcpyDeviceToHost));
   uint64_t* out = (uint64_t*)host_out;
-  for (size_t i = 0; i < count; ++i)
-    out[i] = p->elem_bytes == 8 ? ((const Tw64*)raw.data())[i].w : ((const Tw32*)raw.data())[i].w;
+  const bool split = p->lazy && p->elem_bytes == 8 && (which == 4 || which == 5);
+  for (size_t i = 0; i < count; ++i) {
+    if (p->elem_bytes == 8) out[i] = split ? h_split_value(((const Tw64*)raw.data())[i], p->k) : ((const Tw64*)raw.data())[i].w;
+    else out[i] = ((const Tw32*)raw.data())[i].w;
+  }
   return TN_OK;
 }
 

@@ -24,20 +24,10 @@
 #include <type_traits>
 #include "modarith.h"
 
-// Timing-ablation switches (developer experiments only; results are wrong when set).
-#ifndef TN_BFLY_FENCE
-#define TN_BFLY_FENCE 0          // >0: scheduling fence after every TN_BFLY_FENCE twiddle groups of a stage
+#ifndef TN_BFLY_GROUP
+#define TN_BFLY_GROUP 0          // >0: scheduling fence after every TN_BFLY_GROUP butterflies of a stage (bounds the temporaries in flight)
 #endif
-#ifndef TN_PREFETCH_LAST
-#define TN_PREFETCH_LAST 2       // last-phase (thread-private) twiddles: 0 = loaded at use; 1 = one stage early (28 VGPRs live
-                                 // through a butterfly stage: spills at 128); 2 = just before the transpose that precedes the phase
-#endif
-#ifndef TN_TW_AHEAD
-#define TN_TW_AHEAD 0            // scalar (wave-uniform) twiddles: 1 = requested one butterfly stage before their use, so the
-                                 // scalar-cache / L2 latency hides behind a stage of arithmetic; 0 = loaded at use.
-                                 // Measured on MI355X (n=4096, 60-bit): 1 is 2% SLOWER (3.28 vs 3.21 ms) - the kernel runs
-                                 // at the package power cap, where hidden stalls buy nothing and the fences cost ILP.
-#endif
+// Timing-ablation switch (developer experiments only; results are wrong when set).
 #ifndef TN_ABL_UNIFORM_TW
 #define TN_ABL_UNIFORM_TW 0      // 1: every thread uses the phase-0 (wave-uniform) twiddle indices -> no vector twiddle loads
 #endif
@@ -50,15 +40,30 @@ template <int B, int E_, typename F> struct StaticFor {
 template <int E_, typename F> struct StaticFor<E_, E_, F> { TN_HD static void run(F&) {} };
 template <int B, int E_, typename F> TN_HD void static_for(F&& f) { StaticFor<B, E_, F>::run(f); }
 
+// Coefficients per thread (log2) of the fused kernels for each supported n = 2^logn (0: not built).
+#ifndef TN_FUSED_LPT10
+#define TN_FUSED_LPT10 3         // n = 1024 (8 per thread: 219 vs 188 M products/s at 24 bits)
+#endif
+#ifndef TN_FUSED_LPT12
+#define TN_FUSED_LPT12 3         // n = 4096
+#endif
+constexpr int fused_lpt(int logn) {
+  return logn == 8 ? 2 : logn == 9 ? 3 : logn == 10 ? TN_FUSED_LPT10 : logn == 11 ? 3 : logn == 12 ? TN_FUSED_LPT12 : 0;
+}
+
 // Per-plan arithmetic constants, passed by value to kernels (lives in SGPRs).
 template <typename E> struct Arith {
   E q;
   u64 mu;        // floor(2^(2k)/q)
   int k;         // bitlen(q)
   u32 fold_c;    // 2^k - q (lazy policies only)
-  typename TwOf<E>::type one;        // w = 1 (used to canonicalise arbitrary inputs)
-  typename TwOf<E>::type ninv;       // n^-1
-  typename TwOf<E>::type ninv_w1;    // n^-1 * psi_inv_brv[1]  (last inverse stage, odd half)
+  SplitK sk;     // split-constant product (lazy 64-bit lanes): 2^p, 2^(p+32) mod q
+  typename TwOf<E>::type one;        // w = 1 (used to canonicalise arbitrary inputs); Shoup record
+  typename TwOf<E>::type ninv;       // n^-1, Shoup record (constant-geometry kernels)
+  // last inverse stage of the fused kernels, in the record format of the plan's fused tables
+  // (split for lazy 64-bit plans, Shoup otherwise):
+  typename TwOf<E>::type fninv;      // n^-1
+  typename TwOf<E>::type fninv_w1;   // n^-1 * psi_inv_brv[1]  (odd half)
 };
 
 template <typename E, int LOGN_, int LPT_> struct FusedCfg {
@@ -68,8 +73,14 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
   static constexpr int pos(int p) { return (LOGN - (p + 1) * LPT) < 0 ? 0 : (LOGN - (p + 1) * LPT); }
   static constexpr int stage_begin(int p) { return p * LPT; }
   static constexpr int stage_end(int p) { return ((p + 1) * LPT) < LOGN ? ((p + 1) * LPT) : LOGN; }
-  // LDS image used between phase e and e+1:  addr(j) = j + PAD * (j >> SH)   (in elements)
-  static constexpr int ex_pad(int e) { return pos(e + 1) > 0 ? (1 << pos(e + 1)) : (int)(16 / sizeof(E)); }
+  // LDS image used between phase e and e+1:  addr(j) = j + PAD * (j >> SH)   (in elements).  Padded, not XOR-swizzled, so
+  // that the address is ADDITIVE in the register index on both sides of the transpose (ex_base + ex_off below): one
+  // address register per side and immediate offsets, instead of one register per coefficient (which, as loop invariants
+  // of the persistent row loop, cost ~30 VGPRs and pushed the n = 4096 kernel into scratch).
+  // 8-byte lanes, last exchange: one pad element per R coefficients (64-bit accesses on both sides are then
+  // bank-conflict free; no padding makes 128-bit accesses of the owning side AND the 64-bit ones of the other
+  // side conflict free at once: tests/test_lds_banks.py).
+  static constexpr int ex_pad(int e) { return pos(e + 1) > 0 ? (1 << pos(e + 1)) : (sizeof(E) == 8 ? 1 : (int)(16 / sizeof(E))); }
   static constexpr int ex_sh(int e) { return pos(e + 1) > 0 ? pos(e + 1) + LPT : LPT; }
   static constexpr int lay_span(int e, int cnt) { return cnt + ex_pad(e) * (cnt >> ex_sh(e)); }
   // Waves: thread-id bits >= 6.  WB of them; in every phase after the first they are the top
@@ -92,49 +103,34 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
       if (ex_wave_local(e) && lay_span(e, 1 << WSH) > m) m = lay_span(e, 1 << WSH);
     return m;
   }
-  // n = 4096, 64-bit, 8 coefficients per thread: XOR-swizzled images instead of padded ones, so the
-  // transpose buffer is exactly one polynomial (32 KiB) and two workgroups per CU fit beside the
-  // parked operand and the LDS twiddle tables.  With j = (w:3 | g:3 | m:3 | e:3):
-  //   exchange 0 (phase 0 <-> 1): both sides touch 64 contiguous coefficients per wave-instruction: identity;
-  //   exchange 1 (1 <-> 2): m[1:0] ^= g[1:0];
-  //   exchange 2 (2 <-> 3): m[1:0] ^= g[1:0], e[2] ^= m[2] ^ g[1], e[1] ^= m[1]
-  // (bank-conflict free for the ds_{read,write}_b64 / _b128 lane groups of gfx950; checked by
-  // tests/test_lds_banks.py with a bank simulator).
-  static constexpr bool SWZ = (sizeof(E) == 8 && LOGN == 12 && LPT == 3);
   static constexpr int lds_elems() {
-    if (SWZ) return N;
     int m = region_elems() << WB;
     for (int e = 0; e + 1 < PHASES; ++e)
       if (!ex_wave_local(e) && lay_span(e, N) > m) m = lay_span(e, N);
     return m;
   }
-  TN_HD static u32 jidx(int p, u32 tau, u32 r) {
-    const int ps = pos(p);
-    return ((tau >> ps) << (ps + LPT)) | (r << ps) | (tau & ((1u << ps) - 1u));
+  TN_HD static constexpr u32 jidx(int p, u32 tau, u32 r) {
+    return ((tau >> pos(p)) << (pos(p) + LPT)) | (r << pos(p)) | (tau & ((1u << pos(p)) - 1u));
   }
-  TN_HD static u32 ex_addr(int e, u32 j) {
-    if (SWZ) {
-      if (e == 0) return j;
-      const u32 g = (j >> 6) & 7u, m = (j >> 3) & 7u;
-      u32 a = j ^ ((g & 3u) << 3);
-      if (e == 2) a ^= ((((m >> 2) ^ (g >> 1)) & 1u) << 2) | (((m >> 1) & 1u) << 1);
-      return a;
-    }
-    if (WB > 0 && ex_wave_local(e)) {
-      const u32 x = j & ((1u << WSH) - 1u);
-      return (j >> WSH) * (u32)region_elems() + x + (u32)ex_pad(e) * (x >> ex_sh(e));
-    }
+  TN_HD static constexpr u32 ex_addr(int e, u32 j) {
+    if (WB > 0 && ex_wave_local(e))
+      return (j >> WSH) * (u32)region_elems() + (j & ((1u << WSH) - 1u)) + (u32)ex_pad(e) * ((j & ((1u << WSH) - 1u)) >> ex_sh(e));
     return j + (u32)ex_pad(e) * (j >> ex_sh(e));
   }
+  // ex_addr(e, jidx(p, tau, r)) == ex_base(e, p, tau) + ex_off(e, p, r)  for p in {e, e+1}: the thread bits and the
+  // register bits of j are disjoint, and the shift in ex_addr cuts either above or below all register bits
+  // (checked exhaustively by tests/test_lds_banks.py)
+  TN_HD static constexpr u32 ex_base(int e, int p, u32 tau) { return ex_addr(e, jidx(p, tau, 0)); }
+  TN_HD static constexpr u32 ex_off(int e, int p, u32 r) { return ex_addr(e, jidx(p, 0, r)); }
   // Where the twiddles of phase p come from:
   //   TW_UNIFORM  every thread of the workgroup uses the same ones        -> scalar loads
   //   TW_WAVE     the same within a wave (index depends on the wave id)     -> scalar loads
   //   TW_LDS      lane-dependent, table small: staged once per workgroup in LDS
-  //   TW_REGS     last phase: one private set per thread, fetched from the L2-resident table
-  //               one phase ahead into registers (pre[])
+  //   TW_REGS     last phase: one private set per thread, fetched from the L2-resident table into
+  //               registers (pre[]) just before the transpose that precedes the phase
   enum { TW_UNIFORM = 0, TW_WAVE = 1, TW_LDS = 2, TW_REGS = 3 };
   static constexpr int tw_src(int p) {
-    return pos(p) >= LOGN - LPT ? TW_UNIFORM : (pos(p) >= 6 ? TW_WAVE : (pos(p) > 0 ? TW_LDS : (TN_PREFETCH_LAST ? TW_REGS : TW_WAVE)));
+    return pos(p) >= LOGN - LPT ? TW_UNIFORM : (pos(p) >= 6 ? TW_WAVE : (pos(p) > 0 ? TW_LDS : TW_REGS));
   }
   static constexpr int lds_tw_lo() {                 // first table index kept in LDS
     for (int p = 0; p < PHASES; ++p) if (tw_src(p) == TW_LDS) return 1 << stage_begin(p);
@@ -169,50 +165,47 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
 };
 
 // ---------------------------------------------------------------------------
-// Arithmetic policies.  LIMIT = how many multiples of q a lane word can hold.
+// Arithmetic policies.
 //
-// Lazy: values are kept only congruent mod q and bounded by a compile-time
-// multiple of q; "fold" (one Barrett step with estimate x>>k) is inserted by a
-// static schedule when the bound would exceed LIMIT.  Needs q = 2^k - c with c
-// small and LIMIT*q <= 2^W; checked at plan creation (plan.cpp).
+// Lazy: values are kept only congruent mod q and bounded at compile time; "fold" (one Barrett step with
+//   estimate x>>k) is inserted by a static schedule where a bound would overflow the word.  Needs
+//   q = 2^k - c with c small; checked at plan creation (plan_tables.h).
+//   * 64-bit lanes: split-constant twiddle product (mul_sp_acc, modarith.h), bounds tracked per register in
+//     units of 2^k / 4096 by SplitSched below and verified exactly for the plan's (k, c) by h_split_sched_ok().
+//   * 32-bit lanes: Shoup product (< 2q), bounds in multiples of q (Sched below), LIMIT = 64.
 // Canonical: every value in [0,q) after every operation; any odd q < 2^62 / 2^31.
 template <typename E> struct LazyTraits;
-// PW = bound of the lazy pointwise product (pointwise() below)
-template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4, PW = 2; };   // mul_tw_lazy < 4q
+// PW = bound of the lazy pointwise product (pointwise() below), in multiples of q
+template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4, PW = 2; };   // (TMUL: canonical policy's Shoup product, unused by the split path)
 template <> struct LazyTraits<u32> { static constexpr int LIMIT = 64, TMUL = 2, PW = 4; };   // mul_tw_lazy < 2q
-
-// Lazy Cooley-Tukey butterfly: u' = u + t, v' = u - t + TMUL*q with t = v*w mod q + {0..TMUL-1}q.
-// 64-bit lanes: the add of u rides on the mad chain for free, and v' = 2u + 4q - u'
-// (computed mod 2^64; the true value u + 4q - t fits by the lazy bound).
-TN_HD void ct_lazy(u64& u, u64& v, Tw64 w, u64 q) {
-  const u64 x = mul_tw_acc(u, v, w, q);
-  v = ((u << 1) + 4 * q) - x;
-  u = x;
-}
-TN_HD void ct_lazy(u32& u, u32& v, Tw32 w, u32 q) {
-  const u32 t = mul_tw_lazy(v, w, q);                           // < 2q
-  v = u + (2 * q - t);
-  u = u + t;
-}
 
 template <typename E, bool LAZY> struct Policy {
   typedef typename TwOf<E>::type Tw;
   static constexpr bool lazy = LAZY;
+  static constexpr bool split = LAZY && sizeof(E) == 8;
   static constexpr int LIMIT = LazyTraits<E>::LIMIT, TMUL = LazyTraits<E>::TMUL, PW = LazyTraits<E>::PW;
 
-  // value bound (in multiples of q) after loading an arbitrary word
+  // an arbitrary word -> a bounded lazy value (< 2^k + eps) or a canonical one
   TN_HD static E load(E x, const Arith<E>& ar) {
-    if (LAZY) return fold(x, ar.k, ar.fold_c);                 // < 2q
-    return mul_tw(x, ar.one, ar.q);                            // canonical
+    if (LAZY) return fold(x, ar.k, ar.fold_c);
+    return mul_tw(x, ar.one, ar.q);
   }
-  TN_HD static E canon(E x, const Arith<E>& ar) {              // any bounded lazy value -> [0,q)
+  TN_HD static E canon(E x, const Arith<E>& ar) {              // any lazy value -> [0,q)
     if (LAZY) { x = fold(x, ar.k, ar.fold_c); return csub(x, ar.q); }
     return x;
   }
-  // Cooley-Tukey: (u, v) -> (u + w v, u - w v)
-  TN_HD static void ct(E& u, E& v, Tw w, const Arith<E>& ar) {
-    if (LAZY) {
-      ct_lazy(u, v, w, ar.q);
+  // Cooley-Tukey: (u, v) -> (u + w v, u - w v).  K: the lazy product is below K q (schedule constant).
+  //   split: x = u + t' rides the multiply-add chain; the other output is 2u + K q - x = u + K q - t'
+  //   (mod 2^64; the true value fits by the schedule's bound).
+  template <int K> TN_HD static void ct(E& u, E& v, Tw w, const Arith<E>& ar) {
+    if constexpr (split) {
+      const u64 x = mul_sp_acc(u, v, w, ar.sk);
+      v = ((u << 1) + (u64)K * ar.q) - x;
+      u = x;
+    } else if constexpr (LAZY) {
+      const E t = mul_tw_lazy(v, w, ar.q);                       // < 2q
+      v = u + ((E)K * ar.q - t);
+      u = u + t;
     } else {
       E t = mul_tw(v, w, ar.q);
       E s = u + t;
@@ -220,12 +213,13 @@ template <typename E, bool LAZY> struct Policy {
       u = csub(s, ar.q);
     }
   }
-  // Gentleman-Sande: (u, v) -> (u + v, (u - v) w);  BND = compile-time bound of u, v
+  // Gentleman-Sande: (u, v) -> (u + v, (u - v) w);  v < BND q
   template <int BND> TN_HD static void gs(E& u, E& v, Tw w, const Arith<E>& ar) {
-    if (LAZY) {
-      E d = u + ((E)BND * ar.q - v);
+    if constexpr (LAZY) {
+      const E d = u + ((E)BND * ar.q - v);
       u = u + v;
-      v = mul_tw_lazy(d, w, ar.q);
+      if constexpr (split) v = mul_sp(d, w, ar.sk);
+      else v = mul_tw_lazy(d, w, ar.q);
     } else {
       E d = u >= v ? u - v : u + (ar.q - v);
       u = csub(u + v, ar.q);
@@ -235,19 +229,20 @@ template <typename E, bool LAZY> struct Policy {
   // last inverse stage, n^-1 folded in, canonical outputs
   template <int BND> TN_HD static void gs_last(E& u, E& v, const Arith<E>& ar) {
     E d = LAZY ? (E)(u + ((E)BND * ar.q - v)) : (u >= v ? (E)(u - v) : (E)(u + (ar.q - v)));
-    E s = u + v;                                               // < 2 BND q (lazy) or < 2q: fits the word
-    u = mul_tw_canon(s, ar.ninv, ar);
-    v = mul_tw_canon(d, ar.ninv_w1, ar);
+    E s = u + v;                                               // fits the word by the schedule's bound
+    u = mul_tw_canon(s, ar.fninv, ar);
+    v = mul_tw_canon(d, ar.fninv_w1, ar);
   }
-  // canonical twiddle product.  Lazy 64-bit lanes: the product lies in [0, 4q); one fold puts it below 2q,
-  // so ONE conditional subtraction finishes instead of two (24 instead of 32 issue cycles).
+  // canonical twiddle product.  Split: the product is below 7 * 2^k for any word; one fold puts it below 2q,
+  // so ONE conditional subtraction finishes.
   TN_HD static E mul_tw_canon(E a, Tw w, const Arith<E>& ar) {
-    if (LAZY && sizeof(E) == 8) return csub(fold(mul_tw_lazy(a, w, ar.q), ar.k, ar.fold_c), ar.q);
-    return mul_tw(a, w, ar.q);
+    if constexpr (split) return csub(fold(mul_sp(a, w, ar.sk), ar.k, ar.fold_c), ar.q);
+    else return mul_tw(a, w, ar.q);
   }
 };
 
-// Static fold schedule.  fwd: bound grows by TMUL per stage.  inv: bound -> max(2B, TMUL).
+// Static fold schedule of the 32-bit lazy policy (and the trivial one of the canonical policy), in multiples
+// of q.  fwd: bound grows by TMUL per stage.  inv: bound -> max(2B, TMUL).
 template <typename P, int LOGN> struct Sched {
   // bound BEFORE forward stage s (after an optional fold)
   static constexpr int fwd_in(int s) {
@@ -271,6 +266,117 @@ template <typename P, int LOGN> struct Sched {
   static constexpr int inv_bnd(int g) { return inv_fold(g) ? 2 : inv_in(g); }
 };
 
+// Bound schedule of the split-constant policy (lazy 64-bit lanes), per register, in units of 2^k / 4096,
+// laid out for the worst case k = 60 (2^64 = 16 * 2^k; smaller k only has more room).  Every value of the
+// transform has a compile-time upper bound; the schedule decides where a fold() is needed and which multiple
+// K of q makes a difference non-negative.  Within a register phase bounds are tracked per register; an LDS
+// transpose mixes registers of different threads, so the next phase starts from their maximum.
+//   product of a value below bv:  t' < tmax(bv) = 2^(k+1) + bv/8 + 2^(k+1) + 2^32 cf   (mul_sp_acc)
+//   Cooley-Tukey (u, v):  K = ceil(tmax(bv) / q);  needs u + max(tmax, K q) <= 2^64, else u is folded first;
+//                         outputs u + tmax(bv), u + K q
+//   Gentleman-Sande (u, v):  Kv = ceil(bv / q);  needs u + Kv q <= 2^64 and u + v <= 2^64, else the larger is
+//                         folded first; outputs u + v, tmax(u + Kv q)
+// The decisions are compile-time guesses in coarse units; h_split_sched_ok() (plan_tables.h) replays them with
+// exact 128-bit bounds for the plan's (k, c), and a plan whose modulus fails that replay is not lazy.
+template <typename Cfg> struct SplitSched {
+  static constexpr int LOGN = Cfg::LOGN, R = Cfg::R;
+  static constexpr long U = 4096, CAP = 16 * U;
+  static constexpr long FOLDED = U + 1;            // fold(): < 2^k + 2^(64-k) c
+  static constexpr long PW_OUT = 2 * U;            // mulmod_solinas_lazy: < 2q
+  static constexpr long PW_IN = 14 * (U - 1);      // ... for an unfolded operand below 14 q
+  static constexpr long tmax(long bv) { return 4 * U + (bv + 7) / 8 + 2; }
+  static constexpr int kq(long b) { return (int)((b + U - 2) / (U - 1)); }      // smallest K with K q >= b  (q >= (U-1) units)
+  // The multiples K q live in SGPR pairs; only a few distinct ones are used so that they stay resident across the
+  // persistent row loop: 6q or 7q in the forward butterflies, multiples of 4q in the inverse ones (one more fold per
+  // inverse transform than with exact multiples).
+  static constexpr int kf(long t) { return kq(t) <= 6 ? 6 : kq(t); }
+  static constexpr int ki(long b) { return (kq(b) + 3) / 4 * 4; }
+  static constexpr int phase_of(int s) { return s / Cfg::LPT; }
+  static constexpr int bpos_of(int s) { return (LOGN - 1 - s) - Cfg::pos(phase_of(s)); }
+  struct Data {
+    bool ffold[LOGN][R] = {};          // forward stage s: fold register r (a "u" of the stage) first
+    unsigned char fk[LOGN][R] = {};    // forward stage s: K of the butterfly whose u is register r
+    long fout = 0;                     // bound of every forward output
+    bool pw_fold_b = false;            // pointwise: the second operand must be folded too
+    bool ifold[LOGN][R] = {};          // inverse stage g (execution order): fold register r first
+    unsigned char ik[LOGN][R] = {};    // inverse stage g: Kv of the butterfly whose u is register r
+  };
+  static constexpr Data build() {
+    Data d;
+    long b[R] = {};
+    // forward: load_reduce() folds the registers that enter stage 0 as "u" (the low half), the rest are raw words
+    for (int r = 0; r < R; ++r) b[r] = r < R / 2 ? FOLDED : CAP;
+    for (int s = 0; s < LOGN; ++s) {
+      if (s > 0 && phase_of(s) != phase_of(s - 1)) {
+        long m = 0;
+        for (int r = 0; r < R; ++r) m = b[r] > m ? b[r] : m;
+        for (int r = 0; r < R; ++r) b[r] = m;
+      }
+      const int bit = 1 << bpos_of(s);
+      for (int r = 0; r < R; ++r) {
+        if (r & bit) continue;
+        const long t = tmax(b[r | bit]);
+        const int K = kf(t);
+        const long grow = t > K * U ? t : K * U;
+        if (b[r] + grow > CAP) { d.ffold[s][r] = true; b[r] = FOLDED; }
+        d.fk[s][r] = (unsigned char)K;
+        const long bu = b[r];
+        b[r] = bu + t;
+        b[r | bit] = bu + K * U;
+      }
+    }
+    for (int r = 0; r < R; ++r) d.fout = b[r] > d.fout ? b[r] : d.fout;
+    d.pw_fold_b = d.fout > PW_IN;
+    // inverse, execution order g (g = 0 undoes forward stage LOGN-1)
+    for (int r = 0; r < R; ++r) b[r] = PW_OUT;
+    for (int g = 0; g < LOGN; ++g) {
+      const int s = LOGN - 1 - g;
+      if (g > 0 && phase_of(s) != phase_of(s + 1)) {
+        long m = 0;
+        for (int r = 0; r < R; ++r) m = b[r] > m ? b[r] : m;
+        for (int r = 0; r < R; ++r) b[r] = m;
+      }
+      const int bit = 1 << bpos_of(s);
+      for (int r = 0; r < R; ++r) {
+        if (r & bit) continue;
+        const int v = r | bit;
+        for (int it = 0; it < 2; ++it) {
+          if (b[r] + ki(b[v]) * U <= CAP && b[r] + b[v] <= CAP) break;
+          if (b[r] >= b[v]) { d.ifold[g][r] = true; b[r] = FOLDED; }
+          else { d.ifold[g][v] = true; b[v] = FOLDED; }
+        }
+        const int Kv = ki(b[v]);
+        d.ik[g][r] = (unsigned char)Kv;
+        const long bd = b[r] + Kv * U;
+        b[r] = b[r] + b[v];
+        b[v] = tmax(bd);
+      }
+    }
+    return d;
+  }
+  static constexpr Data D = build();
+};
+
+// What the phase loops ask the schedule of their policy.
+template <typename Pol, typename Cfg> struct SchedOf {
+  typedef Sched<Pol, Cfg::LOGN> S;
+  static constexpr bool fwd_fold(int s, int r) { return S::fwd_fold(s) && !(r & (1 << SplitSched<Cfg>::bpos_of(s))); }
+  static constexpr int fwd_k(int, int) { return Pol::TMUL; }
+  static constexpr bool inv_fold(int g, int) { return S::inv_fold(g); }
+  static constexpr int inv_k(int g, int) { return S::inv_bnd(g); }
+  static constexpr bool pw_fold_b() { return false; }
+  static constexpr bool pw_ok() { return !Pol::lazy || S::fwd_out() <= Pol::LIMIT - 2; }
+};
+template <typename Cfg> struct SchedOf<Policy<u64, true>, Cfg> {
+  typedef SplitSched<Cfg> S;
+  static constexpr bool fwd_fold(int s, int r) { return S::D.ffold[s][r]; }
+  static constexpr int fwd_k(int s, int r) { return S::D.fk[s][r]; }
+  static constexpr bool inv_fold(int g, int r) { return S::D.ifold[g][r]; }
+  static constexpr int inv_k(int g, int r) { return S::D.ik[g][r]; }
+  static constexpr bool pw_fold_b() { return S::D.pw_fold_b; }
+  static constexpr bool pw_ok() { return true; }
+};
+
 // The three places a phase can take its twiddles from (see FusedCfg::tw_src).
 template <typename E> struct TwRefs {
   typedef typename TwOf<E>::type Tw;
@@ -278,6 +384,8 @@ template <typename E> struct TwRefs {
   const Tw* lds;                   // entries [lds_tw_lo, lds_tw_hi) of it, staged in LDS
   Tw* pre;                         // the calling thread's last-phase twiddles, in registers
   const Tw* mid = nullptr;         // optional: the calling thread's twiddles of the LDS-sourced phase, already in registers
+  u32 zero = 0;                    // opaque_zero() of the current row, added to the index of scalar (wave-uniform) twiddle loads:
+                                   // keeps those loads inside the persistent row loop (see polymul_fused_kernel)
 };
 
 template <typename E, typename Cfg, int PH, int S_>
@@ -289,7 +397,7 @@ TN_HD typename TwOf<E>::type tw_get(const TwRefs<E>& t, u32 thi, int g) {
     if (t.mid) return t.mid[(1 << (S_ - Cfg::stage_begin(PH))) - 1 + g];      // stage i of a full phase has 2^i twiddles, starting at 2^i - 1
     return t.lds[idx - Cfg::lds_tw_lo()];
   }
-  return t.glob[idx];
+  return t.glob[idx + t.zero];
 }
 
 // The calling thread's twiddles of an LDS-sourced FULL phase PH (LPT stages: 1 + 2 + ... = R - 1 of them), read into
@@ -307,19 +415,6 @@ TN_HD void tw_fetch_mid(typename TwOf<E>::type (&mid)[Cfg::R], u32 tau, const ty
   });
 }
 
-// Phases whose twiddles are wave-uniform (scalar loads): they are requested one stage ahead (TN_TW_AHEAD).
-template <typename Cfg, int PH> constexpr bool tw_ahead() {
-  return TN_TW_AHEAD && (Cfg::tw_src(PH) == Cfg::TW_UNIFORM || Cfg::tw_src(PH) == Cfg::TW_WAVE);
-}
-// All twiddles one thread uses in stage S_ of phase PH: R >> (bpos + 1) of them.
-template <typename E, typename Cfg, int PH, int S_>
-TN_HD void tw_stage(const TwRefs<E>& t, u32 tau, typename TwOf<E>::type (&w)[Cfg::R / 2]) {
-  constexpr int bpos = (Cfg::LOGN - 1 - S_) - Cfg::pos(PH);
-  const u32 thi = Cfg::thi(PH, tau);
-#pragma unroll
-  for (int g = 0; g < (Cfg::R >> (bpos + 1)); ++g) w[g] = tw_get<E, Cfg, PH, S_>(t, thi, g);
-}
-
 // Fetch the calling thread's last-phase twiddles into registers (issued ahead of their use).
 template <typename E, typename Cfg>
 TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
@@ -334,108 +429,83 @@ TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename 
       pre[Cfg::pre_off(s) + g] = glob[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g];
   });
 }
+
+// ... only those of stages [S0, S1) of the last phase
+template <typename E, typename Cfg, int S0, int S1>
+TN_HD void tw_prefetch_part(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+  constexpr int PH = Cfg::PHASES - 1;
+  if (Cfg::tw_src(PH) != Cfg::TW_REGS) return;
+  const u32 thi = Cfg::thi(PH, tau);
+  static_for<S0, S1>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+#pragma unroll
+    for (int g = 0; g < Cfg::pre_count(s); ++g)
+      pre[Cfg::pre_off(s) + g] = glob[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g];
+  });
+}
 template <typename E, typename Cfg>
 TN_HD void tw_prefetch(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
   tw_prefetch_raw<E, Cfg>(pre, tau, glob);
 }
 
+// ordinal of the butterfly whose "u" is register r among those of its stage (bit bpos of r is clear)
+constexpr int bfly_index(int r, int bpos) { return ((r >> (bpos + 1)) << bpos) | (r & ((1 << bpos) - 1)); }
+
 // ---------------------------------------------------------------------------
 // One forward phase on a thread's registers.
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, typename TwOf<E>::type (&cur)[Cfg::R / 2]) {
-  // cur[]: with tw_ahead<PH>, the first stage's twiddles, already requested by the caller (before the transpose
-  // that precedes this phase); each stage then requests the next stage's before its own butterflies.
-  typedef Sched<Pol, Cfg::LOGN> S;
+TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+  typedef SchedOf<Pol, Cfg> SO;
   typedef typename TwOf<E>::type Tw;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
-    // the next (last) phase's thread-private twiddles are requested from L2 one stage early
-    if (TN_PREFETCH_LAST == 1 && Cfg::PHASES >= 2 && PH == Cfg::PHASES - 2 && s == Cfg::stage_end(PH) - 1 &&
-        Cfg::tw_src(Cfg::PHASES - 1) == Cfg::TW_REGS) {
-      sched_fence();
-      tw_prefetch_raw<E, Cfg>(tw.pre, tau, tw.glob);
-      sched_fence();
-    }
-    // scalar loads return out of order, so a wait for cur[] also waits for everything requested after it:
-    // the next stage's twiddles are therefore requested right AFTER this stage's first butterfly has consumed cur[]
-    Tw nxt[Cfg::R / 2];
-    constexpr bool AHEAD = tw_ahead<Cfg, PH>() && s + 1 < Cfg::stage_end(PH);
-    if (S::fwd_fold(s)) {
-      // only the "u" side of this stage's butterflies needs its bound back: the "v" side goes through the
-      // twiddle multiply, which accepts any word; both outputs then inherit u's bound + TMUL
-#pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) if (!(r & (1 << bpos))) x[r] = fold(x[r], ar.k, ar.fold_c);
-    }
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) {
-      if (r & (1 << bpos)) continue;
-      const Tw w = tw_ahead<Cfg, PH>() ? cur[r >> (bpos + 1)] : tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
-      Pol::ct(x[r], x[r | (1 << bpos)], w, ar);
-      if constexpr (AHEAD) if (r == 0) {
-        sched_fence();
-        tw_stage<E, Cfg, PH, (AHEAD ? s + 1 : s)>(tw, tau, nxt);
-        sched_fence();
+    // only the "u" side of a butterfly can need its bound back: the "v" side goes through the twiddle
+    // multiply, which accepts any word
+    static_for<0, Cfg::R>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (Pol::lazy && SO::fwd_fold(s, r)) x[r] = fold(x[r], ar.k, ar.fold_c);
+    });
+    static_for<0, Cfg::R>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (!(r & (1 << bpos))) {
+        const Tw w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
+        Pol::template ct<SO::fwd_k(s, r)>(x[r], x[r | (1 << bpos)], w, ar);
+        if constexpr (TN_BFLY_GROUP > 0 && bfly_index(r, bpos) % TN_BFLY_GROUP == TN_BFLY_GROUP - 1) sched_fence();
       }
-      if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
-    }
-    if constexpr (AHEAD) {
-#pragma unroll
-      for (int g = 0; g < Cfg::R / 2; ++g) cur[g] = nxt[g];
-    }
+    });
   });
 }
-template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
-  typename TwOf<E>::type cur[Cfg::R / 2];
-  if constexpr (tw_ahead<Cfg, PH>()) tw_stage<E, Cfg, PH, Cfg::stage_begin(PH)>(tw, tau, cur);
-  fwd_phase<E, Cfg, Pol, PH>(x, tau, tw, ar, cur);
-}
 
-// One inverse phase (stages of phase PH in reverse order).  cur[]: as in fwd_phase (first executed stage = stage_end - 1).
+// One inverse phase (stages of phase PH in reverse order).
 template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, typename TwOf<E>::type (&cur)[Cfg::R / 2]) {
-  typedef Sched<Pol, Cfg::LOGN> S;
+TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
+  typedef SchedOf<Pol, Cfg> SO;
   typedef typename TwOf<E>::type Tw;
   const u32 thi = Cfg::thi(PH, tau);
   static_for<0, Cfg::stage_end(PH) - Cfg::stage_begin(PH)>([&](auto i_) {
     constexpr int s = Cfg::stage_end(PH) - 1 - decltype(i_)::value;   // forward stage number being undone
     constexpr int g = Cfg::LOGN - 1 - s;                               // execution order of the inverse
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
-    Tw nxt[Cfg::R / 2];
-    constexpr bool AHEAD = tw_ahead<Cfg, PH>() && s - 1 >= Cfg::stage_begin(PH) && s - 1 >= 1;   // stage 0 uses ar.ninv*
-    if (S::inv_fold(g)) {
-#pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) x[r] = fold(x[r], ar.k, ar.fold_c);
-    }
-    constexpr int BND = S::inv_bnd(g);
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) {
-      if (r & (1 << bpos)) continue;
-      if (s == 0) Pol::template gs_last<BND>(x[r], x[r | (1 << bpos)], ar);
-      else {
-        const Tw w = tw_ahead<Cfg, PH>() ? cur[r >> (bpos + 1)] : tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
-        Pol::template gs<BND>(x[r], x[r | (1 << bpos)], w, ar);
+    static_for<0, Cfg::R>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (Pol::lazy && SO::inv_fold(g, r)) x[r] = fold(x[r], ar.k, ar.fold_c);
+    });
+    static_for<0, Cfg::R>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (!(r & (1 << bpos))) {
+        constexpr int BND = SO::inv_k(g, r);
+        if constexpr (s == 0) Pol::template gs_last<BND>(x[r], x[r | (1 << bpos)], ar);
+        else {
+          const Tw w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
+          Pol::template gs<BND>(x[r], x[r | (1 << bpos)], w, ar);
+        }
+        if constexpr (TN_BFLY_GROUP > 0 && bfly_index(r, bpos) % TN_BFLY_GROUP == TN_BFLY_GROUP - 1) sched_fence();
       }
-      if constexpr (AHEAD) if (r == 0) {
-        sched_fence();
-        tw_stage<E, Cfg, PH, (AHEAD ? s - 1 : s)>(tw, tau, nxt);
-        sched_fence();
-      }
-      if (TN_BFLY_FENCE && (r >> (bpos + 1)) % TN_BFLY_FENCE == TN_BFLY_FENCE - 1 && ((r & ((1 << bpos) - 1)) == (1 << bpos) - 1)) sched_fence();
-    }
-    if constexpr (AHEAD) {
-#pragma unroll
-      for (int g2 = 0; g2 < Cfg::R / 2; ++g2) cur[g2] = nxt[g2];
-    }
+    });
   });
-}
-template <typename E, typename Cfg, typename Pol, int PH>
-TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar) {
-  typename TwOf<E>::type cur[Cfg::R / 2];
-  if constexpr (tw_ahead<Cfg, PH>() && Cfg::stage_end(PH) - 1 >= 1) tw_stage<E, Cfg, PH, Cfg::stage_end(PH) - 1>(tw, tau, cur);
-  inv_phase<E, Cfg, Pol, PH>(x, tau, tw, ar, cur);
 }
 
 // Reduction of freshly loaded operand words before the first forward stage: only the registers that enter
@@ -446,41 +516,24 @@ TN_HD void load_reduce(E (&x)[Cfg::R], const Arith<E>& ar) {
   for (int r = 0; r < Cfg::R / 2; ++r) x[r] = Pol::load(x[r], ar);
 }
 
-// LDS transposes.  e = exchange index (between phase e and e+1); `from` = phase
-// whose register layout is being written, `to` = phase whose layout is read.
-struct alignas(16) Pair64 { u64 lo, hi; };
+// LDS transposes.  EX = exchange index (between phase EX and EX+1); PH = the phase whose register layout is
+// written / read.  One address per thread and side, immediate offsets per register.
 template <typename E, typename Cfg, int EX, int PH>
 TN_HD void ex_store(const E (&x)[Cfg::R], u32 tau, E* lds) {
-  if constexpr (Cfg::SWZ && Cfg::pos(PH) == 0) {       // thread owns 8 consecutive coefficients: 16-byte stores
-#pragma unroll
-    for (int r = 0; r < Cfg::R; r += 2) {
-      Pair64 v; v.lo = x[r]; v.hi = x[r + 1];
-      *reinterpret_cast<Pair64*>(lds + Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))) = v;
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))] = x[r];
-  }
+  E* base = lds + Cfg::ex_base(EX, PH, tau);
+  static_for<0, Cfg::R>([&](auto r_) { constexpr int r = decltype(r_)::value; base[Cfg::ex_off(EX, PH, r)] = x[r]; });
 }
 template <typename E, typename Cfg, int EX, int PH>
 TN_HD void ex_load(E (&x)[Cfg::R], u32 tau, const E* lds) {
-  if constexpr (Cfg::SWZ && Cfg::pos(PH) == 0) {
-#pragma unroll
-    for (int r = 0; r < Cfg::R; r += 2) {
-      const Pair64 v = *reinterpret_cast<const Pair64*>(lds + Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r)));
-      x[r] = (E)v.lo; x[r + 1] = (E)v.hi;
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) x[r] = lds[Cfg::ex_addr(EX, Cfg::jidx(PH, tau, r))];
-  }
+  const E* base = lds + Cfg::ex_base(EX, PH, tau);
+  static_for<0, Cfg::R>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r] = base[Cfg::ex_off(EX, PH, r)]; });
 }
 
 // Pointwise product in the last phase's register layout.  Canonical policy: canonical result.
 // Lazy policy: operands are folded below 2^k + eps and the product is left below LazyTraits::PW q
-// (Sched::inv_in starts from that bound).  64-bit lanes: split-and-fold product; a plan is only lazy
+// (the inverse schedule starts from that bound).  64-bit lanes: split-and-fold product; a plan is only lazy
 // if its (k, c) passes h_pw_fast_ok().  Only ONE operand needs folding first: the other may be any value
-// below (LIMIT - 2) q, which the forward schedule guarantees (Sched::fwd_out, asserted in pointwise()).
+// below 14 q, which the forward schedule guarantees or repairs (SchedOf::pw_fold_b).
 TN_HD u64 pointwise_lazy(u64 a, u64 b, const Arith<u64>& ar) {
   return mulmod_solinas_lazy(fold(a, ar.k, ar.fold_c), b, ar.k, ar.fold_c);       // < 2q
 }
@@ -489,11 +542,12 @@ TN_HD u32 pointwise_lazy(u32 a, u32 b, const Arith<u32>& ar) {
 }
 template <typename E, typename Cfg, typename Pol>
 TN_HD void pointwise(E (&xa)[Cfg::R], const E (&xb)[Cfg::R], const Arith<E>& ar) {
-  static_assert(!Pol::lazy || Sched<Pol, Cfg::LOGN>::fwd_out() <= Pol::LIMIT - 2, "pointwise_lazy: unfolded operand bound");
+  typedef SchedOf<Pol, Cfg> SO;
+  static_assert(SO::pw_ok(), "pointwise_lazy: unfolded operand bound");
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) {
     if (Pol::lazy)
-      xa[r] = pointwise_lazy(xa[r], xb[r], ar);
+      xa[r] = pointwise_lazy(xa[r], SO::pw_fold_b() ? fold(xb[r], ar.k, ar.fold_c) : xb[r], ar);
     else
       xa[r] = mulmod_barrett(xa[r], xb[r], ar.q, ar.mu, ar.k);
     if (r & 1) sched_fence();          // two products in flight at a time: bounds the live temporaries

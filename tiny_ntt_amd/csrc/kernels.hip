@@ -34,29 +34,20 @@
 #ifndef TN_NT_STREAM
 #define TN_NT_STREAM 1           // 1: non-temporal loads/stores for the streamed operands a, b, c
 #endif
-#ifndef TN_PARK_LDS
-#define TN_PARK_LDS 0            // 1: A^ always waits in LDS while b is transformed; 0: in registers wherever that does not spill
-                                 //    (2 % faster, 32 KiB less LDS; see fused_parks())
-#endif
-#ifndef TN_FUSED_LPT10
-#define TN_FUSED_LPT10 3         // log2(coefficients per thread) for n = 1024 (8 per thread: 219 vs 188 M products/s at 24 bits)
-#endif
-#ifndef TN_FUSED_LPT12
-#define TN_FUSED_LPT12 3         // log2(coefficients per thread) for n = 4096
-#endif
 #ifndef TN_FUSED_MIN_WAVES
 #define TN_FUSED_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (4 -> <= 128 VGPRs)
 #endif
 
-#ifndef TN_EX_LOOSE
-#define TN_EX_LOOSE 0            // 1: wave-local transposes without the outer scheduling fences (measured 1 % slower on MI355X)
-#endif
 #ifndef TN_DYNAMIC_ROWS
 #define TN_DYNAMIC_ROWS 1        // 1: persistent workgroups take their next row from a device counter (atomicAdd) instead of a fixed
                                  //    stride: workgroups do not all run at the same speed, and with a fixed share the slowest sets the time
 #endif
 #ifndef TN_SCHED_CHUNK_BYTES
 #define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
+#endif
+#ifndef TN_INV_PREFETCH
+#define TN_INV_PREFETCH 0        // thread-private twiddles of the inverse's first phase: 0 all requested before the pointwise product,
+                                 // 1 only those of its first stage (the rest after the product, when b's registers are free), 2 all after
 #endif
 #ifndef TN_SHARE_MID_TW
 #define TN_SHARE_MID_TW 1        // 1: ... and the phase before it (twiddles staged in LDS) likewise: a: ph 0-1, b: ph 0-1, a: ph 2, b: ph 2, b: ph 3, a: ph 3
@@ -70,11 +61,6 @@
 #define TN_MARK(n)
 #endif
 namespace tn {
-
-// Does the fused product kernel park A^ in LDS while b is transformed?  Not any more: since the fold / pointwise trims
-// every lazy kernel keeps it in registers without spilling (the canonical-policy 64-bit kernel at n = 4096 spills 44
-// bytes per lane either way).
-template <typename E, int LOGN, bool LAZY> constexpr bool fused_parks() { return TN_PARK_LDS != 0; }
 
 // Rows handed out per atomicAdd of the dynamic row scheduler: TN_SCHED_CHUNK_BYTES worth of rows (2 at n = 4096 with
 // 64-bit lanes, 64 at n = 256 with 32-bit lanes) so the one counter address never becomes the bottleneck (one row per
@@ -97,15 +83,11 @@ static inline u32 sched_chunk_rows(size_t row_bytes, size_t batch, size_t reside
 template <typename E, typename Cfg, int EX, int FROM, int TO>
 __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
   if constexpr (Cfg::ex_wave_local(EX)) {
-#if !TN_EX_LOOSE
     __builtin_amdgcn_wave_barrier();
-#endif
     ex_store<E, Cfg, EX, FROM>(x, tau, lds);
     __builtin_amdgcn_wave_barrier();     // lanes read what OTHER lanes of the wave wrote: loads may not move above the stores
     ex_load<E, Cfg, EX, TO>(x, tau, lds);
-#if !TN_EX_LOOSE
     __builtin_amdgcn_wave_barrier();
-#endif
   } else {
 #if TN_ABL_NO_BARRIER
     __builtin_amdgcn_wave_barrier();
@@ -123,47 +105,32 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
   }
 }
 
-// Forward transform, phases [P0, P1).  The thread-private twiddles of the last phase live in pre[]; with `fetch_pre` they
+// Forward transform, phases [P0, P1).  The thread-private twiddles of the last phase live in tw.pre[]; with `fetch_pre` they
 // are requested from L2 just before the transpose that precedes that phase, so their latency hides behind it.
-// first: stage 0's only twiddle (table entry 1), if the caller keeps it resident in registers.
 template <typename E, typename Cfg, typename Pol, int P0, int P1>
-__device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
-                                              const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
-                                              const typename TwOf<E>::type* first, typename TwOf<E>::type (&pre)[Cfg::NPRE], bool fetch_pre,
-                                              const typename TwOf<E>::type* mid = nullptr) {
-  const TwRefs<E> tw = {glob, lds_tw, pre, mid};
-  typename TwOf<E>::type cur[Cfg::R / 2];            // scalar twiddles of the stage about to run (see TN_TW_AHEAD)
-  if constexpr (tw_ahead<Cfg, P0>()) {
-    if (P0 == 0 && first) cur[0] = *first;
-    else tw_stage<E, Cfg, P0, Cfg::stage_begin(P0)>(tw, tau, cur);
-  }
+__device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds, bool fetch_pre,
+                                              u32 tau_g) {      // tau_g: the thread index again, for global addressing (opaque_copy)
   static_for<P0, P1>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     TN_MARK("fwd_phase");
-    fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
+    fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("fwd_other");
-    if constexpr (TN_PREFETCH_LAST == 2 && p == Cfg::PHASES - 2) {
+    if constexpr (p == Cfg::PHASES - 2) {
       if (fetch_pre) {
         sched_fence();                 // request the last phase's private twiddles; they fly during the transpose
-        tw_prefetch<E, Cfg>(pre, tau, glob);
+        tw_prefetch_raw<E, Cfg>(tw.pre, tau_g, tw.glob);
         sched_fence();
       }
     }
-    if constexpr (p + 1 < Cfg::PHASES) {
-      if constexpr (tw_ahead<Cfg, (p + 1 < Cfg::PHASES ? p + 1 : p)>()) {     // next phase's first scalar twiddles fly during the transpose
-        tw_stage<E, Cfg, p + 1, Cfg::stage_begin(p + 1)>(tw, tau, cur);
-        sched_fence();
-      }
-      exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
-    }
+    if constexpr (p + 1 < Cfg::PHASES) exchange<E, Cfg, p, p, p + 1>(x, tau, lds);
   });
 }
 template <typename E, typename Cfg, typename Pol>
 __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob,
-                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds,
-                                            const typename TwOf<E>::type* first = nullptr) {
+                                            const typename TwOf<E>::type* lds_tw, const Arith<E>& ar, E* lds, u32 zero = 0) {
   typename TwOf<E>::type pre[Cfg::NPRE];
-  forward_range<E, Cfg, Pol, 0, Cfg::PHASES>(x, tau, glob, lds_tw, ar, lds, first, pre, true);
+  const TwRefs<E> tw = {glob, lds_tw, pre, nullptr, zero};
+  forward_range<E, Cfg, Pol, 0, Cfg::PHASES>(x, tau, tw, ar, lds, true, tau);
 }
 
 // Inverse transform.  `after_first` runs once the first phase (the one whose thread-private
@@ -173,22 +140,13 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
 template <typename E, typename Cfg, typename Pol, typename F>
 __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds,
                                             F&& after_first) {
-  typename TwOf<E>::type cur[Cfg::R / 2];
-  if constexpr (tw_ahead<Cfg, Cfg::PHASES - 1>() && Cfg::LOGN - 1 >= 1) tw_stage<E, Cfg, Cfg::PHASES - 1, Cfg::LOGN - 1>(tw, tau, cur);
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
     TN_MARK("inv_phase");
-    inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar, cur);
+    inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("inv_other");
     if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
-    if constexpr (p > 0) {
-      constexpr int pn = p > 0 ? p - 1 : 0;
-      if constexpr (tw_ahead<Cfg, pn>() && Cfg::stage_end(pn) - 1 >= 1) {
-        tw_stage<E, Cfg, pn, Cfg::stage_end(pn) - 1>(tw, tau, cur);
-        sched_fence();
-      }
-      exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
-    }
+    if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
   });
 }
 
@@ -203,7 +161,10 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
   row &= TN_ABL_ROWMASK;
 #endif
 #if TN_NT_STREAM
-  return __builtin_nontemporal_load(p + (((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)));   // streamed once: keep L2 for the twiddle tables
+  // address = (row base + the register's offset: wave-uniform, scalar unit) + the thread's offset (ONE vector register for all
+  // R accesses); written out so the compiler does not keep one vector offset per 8 KiB of row (loop invariants it then spills)
+  const E* rp = p + ((size_t)row << Cfg::LOGN) + Cfg::jidx(0, 0, r);
+  return __builtin_nontemporal_load(rp + Cfg::jidx(0, tau, 0));   // streamed once: keep L2 for the twiddle tables
 #else
   return p[((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)];
 #endif
@@ -219,7 +180,7 @@ __device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, c
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) {
 #if TN_NT_STREAM
-    __builtin_nontemporal_store(x[r], c + off + Cfg::jidx(0, tau, r));
+    __builtin_nontemporal_store(x[r], (c + off + Cfg::jidx(0, 0, r)) + Cfg::jidx(0, tau, 0));
 #else
     c[off + Cfg::jidx(0, tau, r)] = x[r];
 #endif
@@ -241,8 +202,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   typedef typename TwOf<E>::type Tw;
   const u32 tau = threadIdx.x;
   // twiddles of the lane-dependent middle phases: staged once per (persistent) workgroup in LDS
-  constexpr bool PARK = fused_parks<E, LOGN, LAZY>();
-  Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems() + (PARK ? Cfg::N : 0));
+  Tw* lds_fwd = reinterpret_cast<Tw*>(lds + Cfg::lds_elems());
   Tw* lds_inv = lds_fwd + Cfg::lds_tw_count();
   u32* lds_next = reinterpret_cast<u32*>(lds_inv + Cfg::lds_tw_count());      // row index this workgroup takes next
   for (u32 i = tau; i < (u32)Cfg::lds_tw_count(); i += Cfg::THREADS) {
@@ -258,10 +218,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // product) while the inverse transform of the current row runs; b itself is requested at the
   // top of the row and not needed until a's forward transform is done.
   E xa[Cfg::R], xb[Cfg::R];
-  const Tw w_stage0 = tab_fwd[1];          // forward stage 0 uses this one twiddle in every row: resident in SGPRs
   u32 row = blockIdx.x * chunk;
-  u32 left = chunk - 1;                     // rows still to take from the current chunk (thread 0's copy is the one used)
-  u32 chunk_id = blockIdx.x;
+  u32 left = chunk - 1;                     // rows still to take from the current chunk   (both workgroup-uniform: scalar registers)
+  u32 chunk_id = blockIdx.x;                // fixed-stride mode: the chunk being processed
   if (row < batch) {
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, row, tau, r);
@@ -278,14 +237,19 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) xa[r] = 0;
   while (row < batch) {
+    // The workgroup-uniform twiddles of the first phase (13 records = 52 SGPRs) are reloaded by the scalar unit in every
+    // row instead of being hoisted out of the loop: hoisted they do not fit the SGPR file and come back through
+    // v_readlane (a vector-ALU slot each), while a scalar load that hits the scalar cache is free.
+    const u32 zero = opaque_zero();
+    const u32 tl = opaque_copy(tau);         // thread index for global addressing within this row (see opaque_copy)
     // one thread determines the next row now; everyone reads the answer after a's transform (barriers in between)
-    if (tau == 0) {
-      if (left) { --left; *lds_next = row + 1; }
-      else {
-        chunk_id = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id + gridDim.x;
-        left = chunk - 1;
-        *lds_next = chunk_id * chunk;
-      }
+    if (left) {
+      --left;
+      if (tau == 0) *lds_next = row + 1;
+    } else {
+      left = chunk - 1;
+      chunk_id += gridDim.x;
+      if (tau == 0) *lds_next = (sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id) * chunk;
     }
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
@@ -296,62 +260,67 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     load_reduce<E, Cfg, Pol>(xn, ar);
     sched_fence();
 #if TN_STORE_AT_TOP
-    st_result<E, Cfg>(c, prev, tau, xa);
+    st_result<E, Cfg>(c, prev, tl, xa);
 #endif
 #pragma unroll
-    for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tau, r);
+    for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(b, row, tl, r);
     sched_fence();
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
-    constexpr bool SHARE = TN_SHARE_LAST_TW && !PARK && Cfg::PHASES >= 2 && TN_PREFETCH_LAST == 2;
+    constexpr bool SHARE = TN_SHARE_LAST_TW && Cfg::PHASES >= 2;
     // SHARE2: the phase before the last is a full LDS-sourced phase: its 2^LPT - 1 twiddles are read into registers once
     constexpr int PM = Cfg::PHASES >= 3 ? Cfg::PHASES - 2 : 0;
     constexpr bool SHARE2 = SHARE && TN_SHARE_MID_TW && Cfg::PHASES >= 3 && Cfg::tw_src(PM) == Cfg::TW_LDS &&
                             Cfg::stage_end(PM) - Cfg::stage_begin(PM) == Cfg::LPT;
     Tw prf[Cfg::NPRE];                       // last forward phase's thread-private twiddles, shared by a and b
-    if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
-    else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
-    else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
-    // (where registers are short) park A^ in a thread-private LDS slot while b is transformed (frees R registers)
-    // slot layout [r/2][thread][2]: every 16-byte access of a wave is contiguous across lanes (conflict-free)
-    PairOf<E>* park = reinterpret_cast<PairOf<E>*>(lds + Cfg::lds_elems()) + tau;
-    if constexpr (PARK) {
-#pragma unroll
-      for (int r = 0; r < Cfg::R; r += 2) { PairOf<E> v; v.lo = xa[r]; v.hi = xa[r + 1]; park[(r / 2) * Cfg::THREADS] = v; }
-    }
+    const TwRefs<E> twf = {tab_fwd, lds_fwd, prf, nullptr, zero};
+    // A^ stays in registers while b is transformed (no spills at 128 VGPRs since the round-1 trims)
+    if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM>(xa, tau, twf, ar, lds, false, tl);
+    else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, twf, ar, lds, false, tl);
+    else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, zero);
     __syncthreads();
     const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
     if constexpr (SHARE2) {
-      forward_range<E, Cfg, Pol, 0, PM>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, false);
+      forward_range<E, Cfg, Pol, 0, PM>(xb, tau, twf, ar, lds, false, tl);
       Tw mid[Cfg::R];
       tw_fetch_mid<E, Cfg, PM>(mid, tau, lds_fwd);
-      forward_range<E, Cfg, Pol, PM, PM + 1>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false, mid);
-      forward_range<E, Cfg, Pol, PM, PM + 1>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, true, mid);
-      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
-      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+      const TwRefs<E> twm = {tab_fwd, lds_fwd, prf, mid, zero};
+      forward_range<E, Cfg, Pol, PM, PM + 1>(xa, tau, twm, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, PM, PM + 1>(xb, tau, twm, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xb, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xa, tau, twf, ar, lds, false, tl);
     } else if constexpr (SHARE) {
-      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0, prf, true);
-      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xb, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
-      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xa, tau, tab_fwd, lds_fwd, ar, lds, nullptr, prf, false);
+      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xb, tau, twf, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xb, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xa, tau, twf, ar, lds, false, tl);
     } else {
-      forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, &w_stage0);
+      forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, zero);
     }
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
-    tw_prefetch<E, Cfg>(pre, tau, tab_inv);
-    if constexpr (PARK) {
-#pragma unroll
-      for (int r = 0; r < Cfg::R; r += 2) { const PairOf<E> v = park[(r / 2) * Cfg::THREADS]; xa[r] = v.lo; xa[r + 1] = v.hi; }
-    }
+#if TN_INV_PREFETCH == 0
+    tw_prefetch<E, Cfg>(pre, tl, tab_inv);
+#elif TN_INV_PREFETCH == 1
+    tw_prefetch_part<E, Cfg, Cfg::LOGN - 1, Cfg::LOGN>(pre, tl, tab_inv);       // the stage the inverse starts with
+#endif
     TN_MARK("pointwise");
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     TN_MARK("after_pointwise");
-    const TwRefs<E> twi = {tab_inv, lds_inv, pre};
+#if TN_INV_PREFETCH == 1
+    sched_fence();
+    tw_prefetch_part<E, Cfg, Cfg::stage_begin(Cfg::PHASES - 1), Cfg::LOGN - 1>(pre, tl, tab_inv);
+    sched_fence();
+#elif TN_INV_PREFETCH == 2
+    sched_fence();
+    tw_prefetch<E, Cfg>(pre, tl, tab_inv);
+    sched_fence();
+#endif
+    const TwRefs<E> twi = {tab_inv, lds_inv, pre, nullptr, zero};
     inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {
       if (next < batch) {              // next row's first operand -> the registers that held b
 #pragma unroll
-        for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tau, r);
+        for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tl, r);
       }
     });
 #if TN_STORE_AT_TOP
@@ -480,7 +449,7 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   Arith<E> ar = pv.ar;
   if (mode == FNTT_TWIST_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_TWIST_FWD>; tab = pv.psi_brv; }
   else if (mode == FNTT_CYCLIC_FWD) { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_FWD>; tab = pv.cyc_brv; }
-  else { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_INV>; tab = pv.cyc_inv_brv; ar.ninv_w1 = ar.ninv; }   // cyc_inv_brv[1] = 1
+  else { kern = (const void*)ntt_fused_kernel<E, LOGN, LPT, LAZY, FNTT_CYCLIC_INV>; tab = pv.cyc_inv_brv; ar.fninv_w1 = ar.fninv; }   // cyc_inv_brv[1] = 1
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -501,14 +470,18 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
 
 template <typename E, bool LAZY>
 static hipError_t launch_nttf_e(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
+#ifdef TN_ONLY_MAIN
+  return hipErrorInvalidValue;
+#else
   switch (p->logn) {
-    case 8: return launch_nttf_t<E, 8, 2, LAZY>(p, mode, in, out, batch, s);
-    case 9: return launch_nttf_t<E, 9, 3, LAZY>(p, mode, in, out, batch, s);
-    case 10: return launch_nttf_t<E, 10, TN_FUSED_LPT10, LAZY>(p, mode, in, out, batch, s);
-    case 11: return launch_nttf_t<E, 11, 3, LAZY>(p, mode, in, out, batch, s);
-    case 12: return launch_nttf_t<E, 12, TN_FUSED_LPT12, LAZY>(p, mode, in, out, batch, s);
+    case 8: return launch_nttf_t<E, 8, fused_lpt(8), LAZY>(p, mode, in, out, batch, s);
+    case 9: return launch_nttf_t<E, 9, fused_lpt(9), LAZY>(p, mode, in, out, batch, s);
+    case 10: return launch_nttf_t<E, 10, fused_lpt(10), LAZY>(p, mode, in, out, batch, s);
+    case 11: return launch_nttf_t<E, 11, fused_lpt(11), LAZY>(p, mode, in, out, batch, s);
+    case 12: return launch_nttf_t<E, 12, fused_lpt(12), LAZY>(p, mode, in, out, batch, s);
     default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s) {
@@ -518,24 +491,12 @@ hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* ou
   return p->lazy ? launch_nttf_e<u32, true>(p, mode, in, out, batch, s) : launch_nttf_e<u32, false>(p, mode, in, out, batch, s);
 }
 
-// log2(n) -> coefficients per thread (log2)
-static int fused_lpt(u32 logn) {
-  switch (logn) {
-    case 8: return 2;
-    case 9: return 3;
-    case 10: return TN_FUSED_LPT10;
-    case 11: return 3;
-    case 12: return TN_FUSED_LPT12;
-    default: return 0;
-  }
-}
-
-bool fused_supported(u32 logn, int) { return fused_lpt(logn) != 0; }
+bool fused_supported(u32 logn, int) { return fused_lpt((int)logn) != 0; }
 
 template <typename E, int LOGN, int LPT, bool LAZY>
 static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
-  const size_t lds_bytes = (size_t)(Cfg::lds_elems() + (fused_parks<E, LOGN, LAZY>() ? Cfg::N : 0)) * sizeof(E) +
+  const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) +
                            (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type) + 16;      // + the next-row slot
   auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
   if (lds_bytes > 48 * 1024) {
@@ -554,7 +515,7 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   // cyclic = product in Z_q[x]/(x^n - 1) (python_poly_mult, test_ntt_poly_mult.py:38-43): same kernel, twiddle
   // tables of the x^n - 1 factorisation tree (HostTables::cyc_brv), whose inverse table has entry 1 equal to 1
   Arith<E> ar = pv.ar;
-  if (cyclic) ar.ninv_w1 = ar.ninv;
+  if (cyclic) ar.fninv_w1 = ar.fninv;
   // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
   u32* sched = nullptr;               // (only pays when every workgroup takes several chunks; a short launch keeps the fixed stride)
   if (TN_DYNAMIC_ROWS && p->d_sched && chunks >= 4 * resident) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
@@ -565,14 +526,19 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
 
 template <typename E, bool LAZY>
 static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
+#ifdef TN_ONLY_MAIN      // developer builds (tools/build_variant.sh -DTN_ONLY_MAIN): only the n = 4096 / 64-bit lazy product kernel
+  if constexpr (!(sizeof(E) == 8 && LAZY)) return hipErrorInvalidValue;
+  else return p->logn == 12 ? launch_fused_t<E, 12, fused_lpt(12), LAZY>(p, a, b, c, batch, s, cyclic) : hipErrorInvalidValue;
+#else
   switch (p->logn) {
-    case 8: return launch_fused_t<E, 8, 2, LAZY>(p, a, b, c, batch, s, cyclic);
-    case 9: return launch_fused_t<E, 9, 3, LAZY>(p, a, b, c, batch, s, cyclic);
-    case 10: return launch_fused_t<E, 10, TN_FUSED_LPT10, LAZY>(p, a, b, c, batch, s, cyclic);
-    case 11: return launch_fused_t<E, 11, 3, LAZY>(p, a, b, c, batch, s, cyclic);
-    case 12: return launch_fused_t<E, 12, TN_FUSED_LPT12, LAZY>(p, a, b, c, batch, s, cyclic);
+    case 8: return launch_fused_t<E, 8, fused_lpt(8), LAZY>(p, a, b, c, batch, s, cyclic);
+    case 9: return launch_fused_t<E, 9, fused_lpt(9), LAZY>(p, a, b, c, batch, s, cyclic);
+    case 10: return launch_fused_t<E, 10, fused_lpt(10), LAZY>(p, a, b, c, batch, s, cyclic);
+    case 11: return launch_fused_t<E, 11, fused_lpt(11), LAZY>(p, a, b, c, batch, s, cyclic);
+    case 12: return launch_fused_t<E, 12, fused_lpt(12), LAZY>(p, a, b, c, batch, s, cyclic);
     default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic) {
@@ -730,8 +696,12 @@ static hipError_t launch_cg_e(const tn_plan* p, int mode, int group, bool padded
 hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out, void* trace,
                      size_t batch, hipStream_t s) {
   if (batch == 0) return hipSuccess;
+#ifdef TN_ONLY_MAIN
+  return hipErrorInvalidValue;
+#else
   if (p->elem_bytes == 8) return launch_cg_e<u64>(p, mode, group, padded, a, b, out, trace, batch, s);
   return launch_cg_e<u32>(p, mode, group, padded, a, b, out, trace, batch, s);
+#endif
 }
 
 const char* cg_kernel_name(const tn_plan*, int, bool) { return "cg_kernel"; }

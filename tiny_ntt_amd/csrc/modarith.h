@@ -15,6 +15,12 @@
 //                 scripts/precompute_constants.py:38-46 and
 //                 rtl/barrett_reduction.v:23-29; used for the pointwise product
 //                 where both operands are data.
+//  * mul_sp_*   — SPLIT-CONSTANT product for q = 2^k - c on the lazy 64-bit path (the butterfly multiply of
+//                 the throughput kernel): the twiddle w is stored as w = wlo + whi 2^p and x = w 2^32 mod q =
+//                 xlo + xhi 2^p with p = k - 31, so  a w == a0 w + a1 x (mod q)  is four 32x32+64 multiply-adds
+//                 in two columns (weights 1 and 2^p), and the 64-bit high column H comes back with two more:
+//                 lo32(H) 2^p (a shift done by the multiplier) and hi32(H) 2^(p+32) == hi32(H) 2c.  Six
+//                 v_mad_u64_u32 and not one other instruction; the butterfly's "+ u" is the first addend.
 //  * fold_*     — for moduli just below a power of two (q = 2^k - c, c small;
 //                 both reference moduli are: 2^23-2^13+1, 2^60-2^14+1) one
 //                 Barrett step with the quotient estimate x >> k:
@@ -41,7 +47,7 @@ typedef uint64_t u64;
 
 // ----------------------------------------------------------------------------
 // Twiddle records: the constant and its precomputed Barrett quotient factor.
-struct Tw64 { u64 w, wp; };   // wp = floor(w * 2^64 / q)
+struct alignas(16) Tw64 { u64 w, wp; };   // wp = floor(w * 2^64 / q); 16-byte aligned: one s_load_dwordx4 / ds_read_b128 / global_load_dwordx4 per record
 struct Tw32 { u32 w, wp; };   // wp = floor(w * 2^32 / q)
 
 template <typename E> struct TwOf;
@@ -72,6 +78,32 @@ TN_HD u32 opaque32(u32 x) {
   asm("" : "+v"(x));
 #endif
   return x;
+}
+
+// The same value as far as the hardware is concerned, a fresh one as far as the compiler is: used on the thread index at
+// the top of the persistent row loop so that (table or operand pointer + thread offset) is NOT a loop invariant.  Hoisted,
+// each such sum is a 64-bit VGPR pair that lives across the whole loop (and ends up in scratch); kept inside the loop the
+// access is "scalar base + 32-bit thread offset", which needs one VGPR for all of them.  No instruction is emitted.
+TN_HD u32 opaque_copy(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
+// A wave-uniform zero the compiler cannot see through, (re)defined at the point of the call.  Adding it to a
+// loop-invariant scalar (a modulus, a table index) pins everything computed or loaded from the sum inside the loop
+// iteration: otherwise the compiler hoists all of it out of the persistent row loop, where there are more such values
+// than SGPRs and they come back through v_readlane (a vector-ALU slot each; recomputing / reloading them on the scalar
+// unit is free).  Costs one v_mov + v_readfirstlane per call.  Host: 0.
+TN_HD u32 opaque_zero() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 z = 0;
+  asm volatile("" : "+v"(z));
+  return (u32)__builtin_amdgcn_readfirstlane((int)z);
+#else
+  return 0;
+#endif
 }
 
 // Scheduling fence (device only): the machine scheduler may not move instructions across it.
@@ -149,6 +181,28 @@ TN_HD u64 mul_tw(u64 a, Tw64 t, u64 q) {
   r = csub(r, 2 * q);
   return csub(r, q);
 }
+
+// ---- split-constant twiddle product (lazy 64-bit lanes, q = 2^k - c, 32 <= k <= 60) ----------------------
+// The 16-byte record is reused: .w = wlo | whi << 32, .wp = xlo | xhi << 32  with  w = wlo + whi 2^p,
+// x = (w 2^32) mod q = xlo + xhi 2^p,  wlo, xlo < 2^p,  whi, xhi < 2^(k-p) = 2^31,  p = k - 31.
+struct SplitK { u32 mulp, cf; };     // 2^p  and  2^(p+32) mod q (= 2c)
+// u + a w (mod q) for ANY 64-bit a, as the integer u + t' with
+//   t' = a0 wlo + a1 xlo + lo32(H) 2^p + hi32(H) cf,   H = a0 whi + a1 xhi < 2^64,
+//   t' < 2^(k+1) + (a >> 32) 2^p + 2^(k+1) + 2^32 cf   (h_sp_tmax() in plan_tables.h evaluates it exactly).
+// The caller's bound schedule guarantees u + t' < 2^64 (SplitSched in fused_core.h, verified for the plan's
+// (k, c) on the host by h_split_sched_ok()).  mulp is a run-time value on purpose: with a literal 2^p the
+// compiler turns that multiply-add into a 64-bit shift and a 64-bit add (two instructions).
+TN_HD u64 mul_sp_acc(u64 u, u64 a, Tw64 t, SplitK sk) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+  u64 L = (u64)a0 * (u32)t.w + u;
+  L = (u64)a1 * (u32)t.wp + L;
+  u64 H = (u64)a0 * (u32)(t.w >> 32);
+  H = (u64)a1 * (u32)(t.wp >> 32) + H;
+  u64 r = (u64)(u32)H * sk.mulp + L;
+  r = (u64)(u32)(H >> 32) * sk.cf + r;
+  return r;
+}
+TN_HD u64 mul_sp(u64 a, Tw64 t, SplitK sk) { return mul_sp_acc(0, a, t, sk); }
 
 // Two-operand Barrett (A9).  a, b in [0, q); k = bitlen(q) in [2, 62]; mu = floor(2^(2k)/q) (<= k+1 bits).
 TN_HD u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu, int k) {
@@ -237,6 +291,12 @@ inline int h_bitlen(u64 x) { int n = 0; while (x) { ++n; x >>= 1; } return n; }
 inline Tw64 h_make_tw64(u64 w, u64 q) {
   Tw64 t; t.w = w; t.wp = (u64)((((unsigned __int128)w) << 64) / q); return t;
 }
+inline Tw64 h_make_tw64_split(u64 w, u64 q, int k) {       // see mul_sp_acc
+  const int p = k - 31;
+  const u64 x = (u64)((((unsigned __int128)w) << 32) % q), m = (((u64)1) << p) - 1;
+  Tw64 t; t.w = (w & m) | ((w >> p) << 32); t.wp = (x & m) | ((x >> p) << 32); return t;
+}
+inline u64 h_split_value(Tw64 t, int k) { return (u64)(u32)t.w + ((t.w >> 32) << (k - 31)); }   // w back from its record
 inline Tw32 h_make_tw32(u64 w, u64 q) {
   Tw32 t; t.w = (u32)w; t.wp = (u32)((w << 32) / q); return t;
 }

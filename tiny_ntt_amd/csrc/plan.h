@@ -15,9 +15,8 @@ struct tn_plan {
   int elem_bytes = 8;
   bool has_fused = false, lazy = false;
   int k = 0;            // bitlen(q)
-  tn::u64 mu = 0;       // floor(2^(2k)/q)
-  tn::u32 fold_c = 0;   // 2^k - q when lazy
-  tn::u64 one_w = 1, one_wp = 0, ninv_w = 0, ninv_wp = 0, ninv_w1_w = 0, ninv_w1_wp = 0;
+  tn::Arith<tn::u64> ar64 = {};    // kernel-argument constants (h_make_arith); the one matching elem_bytes is used
+  tn::Arith<tn::u32> ar32 = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // host-buffer entry points: chunks flow H2D (copy_in) -> kernel (stream) -> D2H (copy_out) through HOST_SLOTS
@@ -26,7 +25,9 @@ struct tn_plan {
   hipStream_t copy_in = nullptr, copy_out = nullptr;
   hipEvent_t ev_in[HOST_SLOTS] = {}, ev_k[HOST_SLOTS] = {}, ev_out[HOST_SLOTS] = {};
   size_t host_chunk_rows = 0;      // rows per chunk; 0 = automatic (HOST_CHUNK_BYTES per operand)
-  // device tables (Tw32[] or Tw64[] according to elem_bytes)
+  // device tables (Tw32[] or Tw64[] according to elem_bytes).  The four tables of the fused kernels (psi_brv, psi_inv_brv,
+  // cyc_brv, cyc_inv_brv) hold split-constant records when the plan is lazy with 64-bit lanes (h_make_fused_tw), every
+  // other table Shoup records {w, floor(w 2^W / q)}.
   void* d_psi_brv = nullptr;       // [n]   psi^brv(i): merged forward twiddles (fused kernel)
   void* d_psi_inv_brv = nullptr;   // [n]   psi^-brv(i)
   void* d_omega_pow = nullptr;     // [n/2] omega^j   (cg_ntt.py:51,54 — pow(omega_s, i//k) = omega^(k*(i//k)))
@@ -65,14 +66,15 @@ template <typename E> struct PlanView {
   const Tw* cyc_inv_brv;
 };
 
+template <typename E> inline const Arith<E>& plan_arith(const tn_plan* p);
+template <> inline const Arith<u64>& plan_arith<u64>(const tn_plan* p) { return p->ar64; }
+template <> inline const Arith<u32>& plan_arith<u32>(const tn_plan* p) { return p->ar32; }
+
 template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
   typedef typename TwOf<E>::type Tw;
   PlanView<E> v;
   v.n = p->n; v.logn = p->logn;
-  v.ar.q = (E)p->q; v.ar.mu = p->mu; v.ar.k = p->k; v.ar.fold_c = p->fold_c;
-  v.ar.one.w = (E)p->one_w; v.ar.one.wp = (E)p->one_wp;
-  v.ar.ninv.w = (E)p->ninv_w; v.ar.ninv.wp = (E)p->ninv_wp;
-  v.ar.ninv_w1.w = (E)p->ninv_w1_w; v.ar.ninv_w1.wp = (E)p->ninv_w1_wp;
+  v.ar = plan_arith<E>(p);
   v.psi_brv = (const Tw*)p->d_psi_brv; v.psi_inv_brv = (const Tw*)p->d_psi_inv_brv;
   v.omega_pow = (const Tw*)p->d_omega_pow; v.omega_inv_pow = (const Tw*)p->d_omega_inv_pow;
   v.psi_pow = (const Tw*)p->d_psi_pow; v.psi_inv_ninv = (const Tw*)p->d_psi_inv_ninv;

@@ -69,6 +69,95 @@ inline bool h_pw_fast_ok(u64 q, int k, u64 c) {
   return rmax < (u128)2 * q;
 }
 
+// ---- split-constant policy (lazy 64-bit lanes): exact replay of SplitSched for the plan's (k, c) -------------
+// All bounds are EXCLUSIVE upper bounds held in 128 bits.
+struct SplitExact {
+  typedef unsigned __int128 u128;
+  int k, p;
+  u64 q, c, cf;
+  u128 two64;
+  bool ok = true;
+  SplitExact(int k_, u64 c_) : k(k_), p(k_ - 31), c(c_) {
+    q = (((u64)1) << k) - c;
+    two64 = ((u128)1) << 64;
+    cf = p >= 1 ? (u64)((((u128)1) << (p + 32)) % q) : 0;
+    if (k < 32 || k > 60 || cf >= ((u64)1 << 32) || c >= ((u64)1 << 32)) ok = false;
+  }
+  // t' of mul_sp_acc for a value below bv (h_sp_tmax): exclusive bound; also checks that H fits 64 bits
+  u128 tmax(u128 bv) {
+    const u128 m32 = (((u128)1) << 32) - 1;
+    u128 a1 = (bv - 1) >> 32; if (a1 > m32) a1 = m32;
+    const u128 wlo = (((u128)1) << p) - 1, whi = (u128)((q - 1) >> p);
+    const u128 H = m32 * whi + a1 * whi;
+    if (H >= two64 || whi > m32) ok = false;
+    return m32 * wlo + a1 * wlo + (m32 << p) + (H >> 32) * cf + 1;
+  }
+  u128 folded(u128 b) { return (((u128)1) << k) + ((b - 1) >> k) * c; }           // fold() of a value below b
+  void fits(u128 exclusive) { if (exclusive > two64) ok = false; }
+};
+
+template <typename Cfg> inline bool h_split_sched_replay(int k, u64 c) {
+  typedef SplitSched<Cfg> S;
+  typedef unsigned __int128 u128;
+  SplitExact x(k, c);
+  if (!x.ok) return false;
+  constexpr int R = Cfg::R, LOGN = Cfg::LOGN;
+  const auto& D = S::D;
+  u128 b[R];
+  auto level = [&]() { u128 m = 0; for (int r = 0; r < R; ++r) m = b[r] > m ? b[r] : m; for (int r = 0; r < R; ++r) b[r] = m; };
+  for (int r = 0; r < R; ++r) b[r] = r < R / 2 ? x.folded(x.two64) : x.two64;       // load_reduce(): low half folded, rest raw words
+  for (int s = 0; s < LOGN; ++s) {
+    if (s > 0 && S::phase_of(s) != S::phase_of(s - 1)) level();
+    const int bit = 1 << S::bpos_of(s);
+    for (int r = 0; r < R; ++r) {
+      if (r & bit) continue;
+      if (D.ffold[s][r]) b[r] = x.folded(b[r]);
+      const u128 t = x.tmax(b[r | bit]), kq = (u128)D.fk[s][r] * x.q;
+      if (kq + 1 < t) x.ok = false;                      // K q >= t'max: the difference output is non-negative
+      x.fits(b[r] - 1 + t); x.fits(b[r] + kq);
+      const u128 bu = b[r];
+      b[r] = bu + t - 1; b[r | bit] = bu + kq;
+    }
+  }
+  u128 fout = 0;
+  for (int r = 0; r < R; ++r) fout = b[r] > fout ? b[r] : fout;
+  if (x.folded(fout) > (u128)2 * x.q) x.ok = false;    // Policy::canon(): fold, one conditional subtraction
+  if (!D.pw_fold_b && fout > (u128)14 * x.q) x.ok = false;       // mulmod_solinas_lazy's unfolded operand (h_pw_fast_ok)
+  for (int r = 0; r < R; ++r) b[r] = (u128)2 * x.q;    // pointwise product: < 2q (h_pw_fast_ok); folded loads are below that too
+  if (x.folded(x.two64) > (u128)2 * x.q) x.ok = false;
+  for (int g = 0; g < LOGN; ++g) {
+    const int s = LOGN - 1 - g;
+    if (g > 0 && S::phase_of(s) != S::phase_of(s + 1)) level();
+    const int bit = 1 << S::bpos_of(s);
+    for (int r = 0; r < R; ++r) if (D.ifold[g][r]) b[r] = x.folded(b[r]);
+    for (int r = 0; r < R; ++r) {
+      if (r & bit) continue;
+      const int v = r | bit;
+      const u128 kq = (u128)D.ik[g][r] * x.q;
+      if (kq + 1 < b[v]) x.ok = false;                   // Kv q >= v: u + Kv q - v is non-negative
+      x.fits(b[r] + kq); x.fits(b[r] + b[v] - 1);
+      const u128 bd = b[r] + kq;
+      b[r] = b[r] + b[v] - 1;
+      b[v] = x.tmax(bd);
+    }
+  }
+  // last inverse stage (gs_last): both outputs go through mul_tw_canon = csub(fold(mul_sp(any word)))
+  if (x.folded(x.tmax(x.two64)) > (u128)2 * x.q) x.ok = false;
+  return x.ok;
+}
+
+// Is the split-constant lazy policy valid for this (n, k, c)?  (false too when no fused kernel is built for n)
+inline bool h_split_sched_ok(u32 logn, int k, u64 c) {
+  switch (logn) {
+    case 8: return h_split_sched_replay<FusedCfg<u64, 8, fused_lpt(8)>>(k, c);
+    case 9: return h_split_sched_replay<FusedCfg<u64, 9, fused_lpt(9)>>(k, c);
+    case 10: return h_split_sched_replay<FusedCfg<u64, 10, fused_lpt(10)>>(k, c);
+    case 11: return h_split_sched_replay<FusedCfg<u64, 11, fused_lpt(11)>>(k, c);
+    case 12: return h_split_sched_replay<FusedCfg<u64, 12, fused_lpt(12)>>(k, c);
+    default: return false;
+  }
+}
+
 // Preconditions (checked by the caller): n = 2^logn >= 4, q odd prime < 2^62, psi^n == -1.
 inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   HostTables t;
@@ -80,6 +169,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   t.mu = (u64)((((unsigned __int128)1) << (2 * t.k)) / q);
   t.lazy = h_lazy_ok(q, t.elem_bytes, &t.fold_c) && allow_lazy;
   if (t.lazy && t.elem_bytes == 8 && !h_pw_fast_ok(q, t.k, t.fold_c)) t.lazy = false;     // 64-bit lazy pointwise product needs it
+  if (t.lazy && t.elem_bytes == 8 && !h_split_sched_ok(logn, t.k, t.fold_c)) t.lazy = false;   // ... and the butterflies this
   if (!t.lazy) t.fold_c = 0;
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72
@@ -113,18 +203,38 @@ template <typename E> inline typename TwOf<E>::type h_make_tw(u64 w, u64 q);
 template <> inline Tw64 h_make_tw<u64>(u64 w, u64 q) { return h_make_tw64(w, q); }
 template <> inline Tw32 h_make_tw<u32>(u64 w, u64 q) { return h_make_tw32(w, q); }
 
+// Shoup records {w, floor(w 2^W / q)}: constant-geometry kernels, canonical policy, 32-bit lanes
 template <typename E> inline std::vector<typename TwOf<E>::type> h_tw_table(const std::vector<u64>& v, u64 q) {
   std::vector<typename TwOf<E>::type> t(v.size());
   for (size_t i = 0; i < v.size(); ++i) t[i] = h_make_tw<E>(v[i], q);
   return t;
 }
 
+// Records of the FUSED kernels' tables: split constants (mul_sp_acc) when the plan is lazy with 64-bit lanes, Shoup otherwise.
+inline bool h_uses_split(const HostTables& t) { return t.lazy && t.elem_bytes == 8; }
+template <typename E> inline typename TwOf<E>::type h_make_fused_tw(u64 w, const HostTables& t) { return h_make_tw<E>(w, t.q); }
+template <> inline Tw64 h_make_fused_tw<u64>(u64 w, const HostTables& t) {
+  return h_uses_split(t) ? h_make_tw64_split(w, t.q, t.k) : h_make_tw64(w, t.q);
+}
+template <typename E> inline std::vector<typename TwOf<E>::type> h_fused_table(const std::vector<u64>& v, const HostTables& t) {
+  std::vector<typename TwOf<E>::type> r(v.size());
+  for (size_t i = 0; i < v.size(); ++i) r[i] = h_make_fused_tw<E>(v[i], t);
+  return r;
+}
+
 template <typename E> inline Arith<E> h_make_arith(const HostTables& t) {
   Arith<E> ar;
   ar.q = (E)t.q; ar.mu = t.mu; ar.k = t.k; ar.fold_c = t.fold_c;
+  ar.sk.mulp = 0; ar.sk.cf = 0;
+  if (h_uses_split(t)) {
+    const int p = t.k - 31;
+    ar.sk.mulp = (u32)1 << p;
+    ar.sk.cf = (u32)((((unsigned __int128)1) << (p + 32)) % t.q);
+  }
   ar.one = h_make_tw<E>(1, t.q);
   ar.ninv = h_make_tw<E>(t.n_inv, t.q);
-  ar.ninv_w1 = h_make_tw<E>(t.ninv_w1, t.q);
+  ar.fninv = h_make_fused_tw<E>(t.n_inv, t);
+  ar.fninv_w1 = h_make_fused_tw<E>(t.ninv_w1, t);
   return ar;
 }
 
