@@ -58,6 +58,8 @@ template <typename E> struct Arith {
   int k;         // bitlen(q)
   u32 fold_c;    // 2^k - q (lazy policies only)
   SplitK sk;     // split-constant product (lazy 64-bit lanes): 2^p, 2^(p+32) mod q
+  u64 qmul[17];  // K q for K = 0..16 (split policy: the multiples that make differences non-negative; read from the
+                 // kernel-argument segment by scalar loads where needed instead of being recomputed or kept in registers)
   typename TwOf<E>::type one;        // w = 1 (used to canonicalise arbitrary inputs); Shoup record
   typename TwOf<E>::type ninv;       // n^-1, Shoup record (constant-geometry kernels)
   // last inverse stage of the fused kernels, in the record format of the plan's fused tables
@@ -200,7 +202,7 @@ template <typename E, bool LAZY> struct Policy {
   template <int K> TN_HD static void ct(E& u, E& v, Tw w, const Arith<E>& ar) {
     if constexpr (split) {
       const u64 x = mul_sp_acc(u, v, w, ar.sk);
-      v = ((u << 1) + (u64)K * ar.q) - x;
+      v = ((u << 1) + ar.qmul[K]) - x;
       u = x;
     } else if constexpr (LAZY) {
       const E t = mul_tw_lazy(v, w, ar.q);                       // < 2q
@@ -215,11 +217,14 @@ template <typename E, bool LAZY> struct Policy {
   }
   // Gentleman-Sande: (u, v) -> (u + v, (u - v) w);  v < BND q
   template <int BND> TN_HD static void gs(E& u, E& v, Tw w, const Arith<E>& ar) {
-    if constexpr (LAZY) {
+    if constexpr (split) {
+      const E d = (u + ar.qmul[BND]) - v;
+      u = u + v;
+      v = mul_sp(d, w, ar.sk);
+    } else if constexpr (LAZY) {
       const E d = u + ((E)BND * ar.q - v);
       u = u + v;
-      if constexpr (split) v = mul_sp(d, w, ar.sk);
-      else v = mul_tw_lazy(d, w, ar.q);
+      v = mul_tw_lazy(d, w, ar.q);
     } else {
       E d = u >= v ? u - v : u + (ar.q - v);
       u = csub(u + v, ar.q);
@@ -228,7 +233,9 @@ template <typename E, bool LAZY> struct Policy {
   }
   // last inverse stage, n^-1 folded in, canonical outputs
   template <int BND> TN_HD static void gs_last(E& u, E& v, const Arith<E>& ar) {
-    E d = LAZY ? (E)(u + ((E)BND * ar.q - v)) : (u >= v ? (E)(u - v) : (E)(u + (ar.q - v)));
+    E d;
+    if constexpr (split) d = (u + ar.qmul[BND]) - v;
+    else d = LAZY ? (E)(u + ((E)BND * ar.q - v)) : (u >= v ? (E)(u - v) : (E)(u + (ar.q - v)));
     E s = u + v;                                               // fits the word by the schedule's bound
     u = mul_tw_canon(s, ar.fninv, ar);
     v = mul_tw_canon(d, ar.fninv_w1, ar);

@@ -45,6 +45,9 @@
 #ifndef TN_SCHED_CHUNK_BYTES
 #define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
 #endif
+#ifndef TN_KARG_ARITH
+#define TN_KARG_ARITH 1          // 1: the product kernel reads its arithmetic constants and scalar twiddles per phase (kernarg_arith)
+#endif
 #ifndef TN_INV_PREFETCH
 #define TN_INV_PREFETCH 0        // thread-private twiddles of the inverse's first phase: 0 all requested before the pointwise product,
                                  // 1 only those of its first stage (the rest after the product, when b's registers are free), 2 all after
@@ -105,14 +108,27 @@ __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
   }
 }
 
+// The kernel's Arith argument as it lies in the kernel-argument segment (first argument of both fused kernels), addressed
+// through an opaque zero: fields are then read by scalar loads AFTER the point where `zero` was defined, i.e. per phase,
+// instead of living in SGPRs (or, spilled, in VGPR lanes) across the whole persistent row loop.
+template <typename E>
+__device__ __forceinline__ const Arith<E>& kernarg_arith(u32 zero) {
+  typedef const __attribute__((address_space(4))) char* KP;
+  return *(const Arith<E>*)((KP)__builtin_amdgcn_kernarg_segment_ptr() + zero);
+}
+
 // Forward transform, phases [P0, P1).  The thread-private twiddles of the last phase live in tw.pre[]; with `fetch_pre` they
 // are requested from L2 just before the transpose that precedes that phase, so their latency hides behind it.
-template <typename E, typename Cfg, typename Pol, int P0, int P1>
-__device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds, bool fetch_pre,
+// KARG: take the arithmetic constants and the scalar twiddles of each phase through a fresh opaque zero (see kernarg_arith).
+template <typename E, typename Cfg, typename Pol, int P0, int P1, bool KARG = false>
+__device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw_in, const Arith<E>& ar_in, E* lds, bool fetch_pre,
                                               u32 tau_g) {      // tau_g: the thread index again, for global addressing (opaque_copy)
   static_for<P0, P1>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
     TN_MARK("fwd_phase");
+    TwRefs<E> tw = tw_in;
+    if constexpr (KARG) tw.zero = opaque_zero();
+    const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("fwd_other");
     if constexpr (p == Cfg::PHASES - 2) {
@@ -137,12 +153,15 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
 // twiddles come from L2 through vector loads) has been computed: vector-memory operations
 // complete in order, so the long-latency HBM prefetch of the next row must be issued AFTER
 // those twiddle loads have been consumed, or every wave would wait for HBM at the top of the inverse.
-template <typename E, typename Cfg, typename Pol, typename F>
-__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E>& ar, E* lds,
+template <typename E, typename Cfg, typename Pol, bool KARG = false, typename F>
+__device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw_in, const Arith<E>& ar_in, E* lds,
                                             F&& after_first) {
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
     TN_MARK("inv_phase");
+    TwRefs<E> tw = tw_in;
+    if constexpr (KARG) tw.zero = opaque_zero();
+    const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("inv_other");
     if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
@@ -267,6 +286,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     sched_fence();
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) xa[r] = xn[r];
+    constexpr bool KARG = TN_KARG_ARITH != 0;
     constexpr bool SHARE = TN_SHARE_LAST_TW && Cfg::PHASES >= 2;
     // SHARE2: the phase before the last is a full LDS-sourced phase: its 2^LPT - 1 twiddles are read into registers once
     constexpr int PM = Cfg::PHASES >= 3 ? Cfg::PHASES - 2 : 0;
@@ -275,25 +295,25 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     Tw prf[Cfg::NPRE];                       // last forward phase's thread-private twiddles, shared by a and b
     const TwRefs<E> twf = {tab_fwd, lds_fwd, prf, nullptr, zero};
     // A^ stays in registers while b is transformed (no spills at 128 VGPRs since the round-1 trims)
-    if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM>(xa, tau, twf, ar, lds, false, tl);
-    else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xa, tau, twf, ar, lds, false, tl);
+    if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM, KARG>(xa, tau, twf, ar, lds, false, tl);
+    else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1, KARG>(xa, tau, twf, ar, lds, false, tl);
     else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, zero);
     __syncthreads();
     const u32 next = wave_uniform(*lds_next);
     load_reduce<E, Cfg, Pol>(xb, ar);
     if constexpr (SHARE2) {
-      forward_range<E, Cfg, Pol, 0, PM>(xb, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, 0, PM, KARG>(xb, tau, twf, ar, lds, false, tl);
       Tw mid[Cfg::R];
       tw_fetch_mid<E, Cfg, PM>(mid, tau, lds_fwd);
       const TwRefs<E> twm = {tab_fwd, lds_fwd, prf, mid, zero};
-      forward_range<E, Cfg, Pol, PM, PM + 1>(xa, tau, twm, ar, lds, false, tl);
-      forward_range<E, Cfg, Pol, PM, PM + 1>(xb, tau, twm, ar, lds, true, tl);
-      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xb, tau, twf, ar, lds, false, tl);
-      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES>(xa, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, PM, PM + 1, KARG>(xa, tau, twm, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, PM, PM + 1, KARG>(xb, tau, twm, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES, KARG>(xb, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES, KARG>(xa, tau, twf, ar, lds, false, tl);
     } else if constexpr (SHARE) {
-      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1>(xb, tau, twf, ar, lds, true, tl);
-      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xb, tau, twf, ar, lds, false, tl);
-      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES>(xa, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1, KARG>(xb, tau, twf, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES, KARG>(xb, tau, twf, ar, lds, false, tl);
+      forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES, KARG>(xa, tau, twf, ar, lds, false, tl);
     } else {
       forward_all<E, Cfg, Pol>(xb, tau, tab_fwd, lds_fwd, ar, lds, zero);
     }
@@ -317,11 +337,12 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     sched_fence();
 #endif
     const TwRefs<E> twi = {tab_inv, lds_inv, pre, nullptr, zero};
-    inverse_all<E, Cfg, Pol>(xa, tau, twi, ar, lds, [&]() {
-      if (next < batch) {              // next row's first operand -> the registers that held b
+    inverse_all<E, Cfg, Pol, KARG>(xa, tau, twi, ar, lds, [&]() {
+      // next row's first operand -> the registers that held b.  Unconditional (after the last row this row's a is read
+      // again and dropped): a branch here costs a register copy of all R values on the path that skips it.
+      const u32 nrow = next < batch ? next : row;
 #pragma unroll
-        for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, next, tl, r);
-      }
+      for (int r = 0; r < Cfg::R; ++r) xb[r] = ld_operand<E, Cfg>(a, nrow, tl, r);
     });
 #if TN_STORE_AT_TOP
     prev = row;

@@ -91,16 +91,16 @@ TN_HD u32 opaque_copy(u32 x) {
   return x;
 }
 
-// A wave-uniform zero the compiler cannot see through, (re)defined at the point of the call.  Adding it to a
-// loop-invariant scalar (a modulus, a table index) pins everything computed or loaded from the sum inside the loop
-// iteration: otherwise the compiler hoists all of it out of the persistent row loop, where there are more such values
-// than SGPRs and they come back through v_readlane (a vector-ALU slot each; recomputing / reloading them on the scalar
-// unit is free).  Costs one v_mov + v_readfirstlane per call.  Host: 0.
+// A wave-uniform zero the compiler cannot see through, (re)defined at the point of the call (one scalar move, no
+// vector-ALU slot).  Adding it to a loop-invariant scalar address or index pins every load that depends on the sum
+// after this point: otherwise the compiler hoists all of them out of the persistent row loop, where there are more such
+// values than SGPRs and they come back through v_readlane (a vector-ALU slot each), while a scalar load that hits the
+// scalar cache is free.  Host: 0.
 TN_HD u32 opaque_zero() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u32 z = 0;
-  asm volatile("" : "+v"(z));
-  return (u32)__builtin_amdgcn_readfirstlane((int)z);
+  u32 z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
 #else
   return 0;
 #endif

@@ -226,6 +226,7 @@ template <typename E> inline Arith<E> h_make_arith(const HostTables& t) {
   Arith<E> ar;
   ar.q = (E)t.q; ar.mu = t.mu; ar.k = t.k; ar.fold_c = t.fold_c;
   ar.sk.mulp = 0; ar.sk.cf = 0;
+  for (int K = 0; K <= 16; ++K) ar.qmul[K] = (u64)(((unsigned __int128)K * t.q) & ~(u64)0);      // K q < 2^64 wherever the schedule uses it
   if (h_uses_split(t)) {
     const int p = t.k - 31;
     ar.sk.mulp = (u32)1 << p;
