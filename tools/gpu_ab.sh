@@ -4,5 +4,5 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 for n in "$@"; do
   if [ "$n" = base ]; then L=$R/tiny_ntt_amd/lib/libtinyntt.so; else L=$R/tiny_ntt_amd/lib/libtinyntt_$n.so; fi
   echo "== $n"
-  TINYNTT_LIB=$L timeout -k 10 120 python $R/tests/dev/gpu_speed.py 65536 fused 2>&1 | grep -E "fused:|checksum|oracle"
+  TINYNTT_LIB=$L timeout -k 10 120 python $R/tests/dev/gpu_speed.py 65536 fused 2>&1 | grep -E "fused:|checksum|oracle" | tr "\n" " "; echo
 done
