@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: batched negacyclic poly-mults/s at n=4096, 60-bit q on N MI355X.
+"""bench.py — headline benchmark: batched negacyclic poly-mults/s on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2] [--rows R | --global-batch B]
 
-A step = one pass of the hot path (tn_poly_mult_dev, fused kernel) over one batch of 65,536
-synthetic polynomial pairs per GPU, inputs resident in HBM (BASELINE.json configs[2]; weak
-scaling: every rank gets its own 65,536-row block of the same global LCG-seeded batch, no
-collective on the data path).  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path (tn_poly_mult_dev, fused kernel) over this rank's block of synthetic
+polynomial pairs, inputs resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json `configs`):
+  cfg3 (default)  n=4096, q=2^60-2^14+1, u64 — the configuration the metric is quoted on.
+      N=1: 65,536 pairs (configs[2]).  N>1: ONE global batch of 2^20 pairs split in contiguous row blocks,
+      rows_g = batch/N (configs[3]) -> "scaling": "strong".  `--rows R` instead gives every
+      rank its own R-row block of the global LCG-seeded batch ("weak"); `--global-batch B` picks B.
+  cfg2            n=1024, q=8380417 (24-bit), u32, batch 4,096 (configs[1]); cpu_baseline from the reference's
+      benchmark_ntt.cpp built for that parameter set (checksum G3 gate).
+No collective on the data path: global row r is make_poly(2r+1) x make_poly(2r+2) on whichever rank owns it.
+
+N>1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK/LOCAL_RANK/
+WORLD_SIZE/MASTER_* from the environment); called WITHOUT that launcher, `--gpus N` starts the N ranks itself
+(fresh child processes, before anything touches the GPU) and exits with their status.
 
 Extra objects on the line:
-  roofline     — algorithmic bytes (3*n*8 B per product: read a, read b, write c)
-                 per launch / mean launch duration measured with HIP events on the plan's stream.
-  cpu_baseline — the reference's own benchmark binary (oracle/_ref, built from the reference
-                 sources in the build container; kind "reference") or this repo's C restatement
-                 of it (kind "port"), timed on this box's host cores for a bounded sample.
-The result is gated on bit-exactness first: row 0 must reproduce the checksum the reference C++
-benchmark prints and sampled rows must equal the on-device O(n^2) direct product (every rank); in the
-cpu_baseline leg (N=1) 64 sampled rows are also compared with the CPU oracle.  Any mismatch aborts the run.
+  roofline      — algorithmic bytes (3*n*w B per product: read a, read b, write c) per launch /
+                  mean launch duration measured with HIP events on the stream the kernel runs on.
+  cpu_baseline  — the reference's own benchmark binary (oracle/_ref, kind "reference") or this repo's C restatement
+                  (kind "port"), timed on this box's host cores for a bounded sample; CPU model and core count stated.
+  control_plane — "rccl" | "gloo" | "none": what carried the barrier / max-reduce, and how many ranks it counted.
+The result is gated on bit-exactness first (every rank): the first global row must reproduce the checksum the reference
+C++ benchmark prints and sampled rows must equal the on-device O(n^2) direct product; in the cpu_baseline leg (N=1)
+64 sampled rows are also compared with the CPU oracle.  Any mismatch aborts the run.
 Order: one checked pass, a fixed device spin-up (40 untimed launches: the shader clock needs ~0.1 s to settle after
 idle), the W warm-up steps, then exactly K timed steps between barriers — so the result does not depend on K or W.
 """
@@ -24,6 +35,7 @@ import argparse
 import ctypes
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -31,32 +43,66 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_COEFF = 4096
-Q = 1152921504606830593                 # 2^60 - 2^14 + 1   (rtl/ntt_poly_mult.sv:18)
-PSI = 431606828070683274                # rtl/ntt_poly_mult.sv:19
-ROWS_PER_GPU = 65536                    # BASELINE.json configs[2]
-REF_CHECKSUM_ROW0 = 2710933653778106521 # printed by benchmark_ntt_60bit_* for make_poly(1) x make_poly(2)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_PRODUCT = 3 * N_COEFF * 8
+
+# parameter sets: SURVEY.md §8 table; checksums: what the reference benchmark prints for make_poly(1) x make_poly(2)
+CONFIGS = {
+    "cfg3": dict(n=4096, q=1152921504606830593, psi=431606828070683274, elem_bytes=8, dtype="u64",          # rtl/ntt_poly_mult.sv:16-24
+                 rows=65536, global_batch=1 << 20, checksum_row0=2710933653778106521,
+                 ref_bins=[f"benchmark_ntt_60bit_{k}" for k in ("avx512", "avx2", "scalar")], port=True,
+                 label="n=4096, q=2^60-2^14+1 (60-bit)", baseline_cfg="BASELINE configs[2]",
+                 metric="negacyclic poly-mults/sec (n=4096, 60-bit q), bit-exact vs cg_ntt.py"),
+    "cfg2": dict(n=1024, q=8380417, psi=5548360, elem_bytes=4, dtype="u32",                                  # test/Makefile:268,276
+                 rows=4096, global_batch=4096, checksum_row0=15308795525113097448,
+                 ref_bins=[f"benchmark_ntt_1024_{k}" for k in ("avx512", "scalar")], port=False,
+                 label="n=1024, q=8380417 (24-bit)", baseline_cfg="BASELINE configs[1]",
+                 metric="negacyclic poly-mults/sec (n=1024, 24-bit q), bit-exact vs cg_ntt.py"),
+}
 
 
-def verify(plan, a, b, c, first_global_row):
-    """Bit-exactness gate on every rank (never timed), without the CPU oracle: (1) row 0 must reproduce the checksum
-    the reference C++ benchmark prints for make_poly(1) x make_poly(2); (2) sampled rows must equal the on-device
-    O(n^2) direct negacyclic product (tn_schoolbook_dev: a different algorithm and kernel, benchmark_ntt_60bit.cpp:167)."""
+def shard_plan(cfg, world, rank, rows_arg=None, global_batch_arg=None):
+    """Which rows of the global LCG-seeded batch this rank owns -> dict(first_row, rows, global_batch, scaling).
+
+    Global row r is always make_poly(2r+1) x make_poly(2r+2), so the union of the rank blocks is
+    the global batch exactly once whatever the split.  N=1 default: cfg['rows'] rows.  N>1 default: cfg['global_batch']
+    rows split rows_g = batch/N (strong scaling, BASELINE configs[3]).  --rows R: R rows per rank (weak scaling)."""
+    from tiny_ntt_amd.dist import shard_rows
+    if rows_arg is not None and global_batch_arg is not None:
+        raise SystemExit("--rows and --global-batch are mutually exclusive")
+    if rows_arg is not None:
+        return dict(first_row=rank * rows_arg, rows=rows_arg, global_batch=rows_arg * world, scaling="weak")
+    if global_batch_arg is None:
+        global_batch_arg = cfg["rows"] if world == 1 else cfg["global_batch"]
+    first, count = shard_rows(global_batch_arg, world, rank)
+    return dict(first_row=first, rows=count, global_batch=global_batch_arg, scaling="weak" if world == 1 else "strong")
+
+
+def seeds_for(first_row):
+    """(seed0 of a, seed0 of b, stride): row i of the block is global row first_row + i."""
+    return 2 * first_row + 1, 2 * first_row + 2, 2
+
+
+def verify(plan, a, b, c, first_global_row, cfg):
+    """Bit-exactness gate on every rank (never timed), without the CPU oracle: (1) global row 0 must reproduce the
+    checksum the reference C++ benchmark prints for make_poly(1) x make_poly(2); (2) sampled rows must equal the
+    on-device O(n^2) direct negacyclic product (tn_schoolbook_dev: a different algorithm and kernel,
+    benchmark_ntt_60bit.cpp:167).  Returns (rows compared, checksum of this rank's first row as computed on device)."""
     import torch
-    sums = plan.checksum_rows(c[:8])
-    if first_global_row == 0 and int(sums[0]) != REF_CHECKSUM_ROW0:
-        raise SystemExit(f"PARITY FAILURE: row 0 checksum {int(sums[0])} != reference {REF_CHECKSUM_ROW0}")
-    idx = list(range(8)) + list(range(a.shape[0] - 8, a.shape[0]))
-    direct = plan.schoolbook(a[idx].contiguous(), b[idx].contiguous())
+    sums = plan.checksum_rows(c[:8], stream="plan")
+    if first_global_row == 0 and int(sums[0]) != cfg["checksum_row0"]:
+        raise SystemExit(f"PARITY FAILURE: row 0 checksum {int(sums[0])} != reference {cfg['checksum_row0']}")
+    k = min(8, a.shape[0])
+    idx = sorted(set(list(range(k)) + list(range(a.shape[0] - k, a.shape[0]))))
+    sa, sb, sc = a[idx].contiguous(), b[idx].contiguous(), c[idx].contiguous()   # gathers run on torch's stream ...
+    torch.cuda.synchronize(a.device)                                               # ... the checker on the plan's (non-blocking) one
+    direct = plan.schoolbook(sa, sb, stream="plan")
     plan.synchronize()
-    if not torch.equal(direct, c[idx]):
+    if not torch.equal(direct, sc):
         raise SystemExit("PARITY FAILURE: sampled rows differ from the direct O(n^2) product")
-    return len(idx)
+    return len(idx), int(sums[0])
 
 
-def oracle_check(plan, a, b, c):
+def oracle_check(plan, a, b, c, cfg):
     """cpu_baseline leg only: 64 sampled rows against the CPU oracle (the checker; never the thing measured)."""
     import numpy as np
     so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
@@ -65,30 +111,43 @@ def oracle_check(plan, a, b, c):
     lib = ctypes.CDLL(so)
     P = ctypes.POINTER(ctypes.c_uint64)
     lib.tn_oracle_nwc_poly_mult_batch.argtypes = [P, P, P, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64]
-    idx = list(range(32)) + list(range(a.shape[0] - 32, a.shape[0]))
+    k = min(32, a.shape[0])
+    idx = sorted(set(list(range(k)) + list(range(a.shape[0] - k, a.shape[0]))))
     ha = np.ascontiguousarray(plan.to_host(a[idx]).astype(np.uint64))
     hb = np.ascontiguousarray(plan.to_host(b[idx]).astype(np.uint64))
     hc = plan.to_host(c[idx]).astype(np.uint64)
     ref = np.empty_like(ha)
-    rc = lib.tn_oracle_nwc_poly_mult_batch(ha.ctypes.data_as(P), hb.ctypes.data_as(P), ref.ctypes.data_as(P), len(idx), N_COEFF, Q, PSI)
+    rc = lib.tn_oracle_nwc_poly_mult_batch(ha.ctypes.data_as(P), hb.ctypes.data_as(P), ref.ctypes.data_as(P), len(idx), cfg["n"], cfg["q"], cfg["psi"])
     if rc != 0 or not np.array_equal(hc, ref):
         raise SystemExit("PARITY FAILURE: sampled rows differ from the CPU oracle")
     return len(idx)
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, budget_s=12.0):
     """Reference benchmark on the host cores: single thread, then one process per core (bounded sample)."""
     cores = min(os.cpu_count() or 1, 16)
     ref_dir, port_dir = os.path.join(ROOT, "oracle", "_ref"), os.path.join(ROOT, "oracle", "_build")
-    candidates = [(os.path.join(ref_dir, f"benchmark_ntt_60bit_{k}"), "reference", k) for k in ("avx512", "avx2", "scalar")]
-    candidates += [(os.path.join(port_dir, f"bench_port{s}"), "port", s.strip("_") or "scalar") for s in ("_avx512", "_avx2", "")]
+    candidates = [(os.path.join(ref_dir, b), "reference", b.rsplit("_", 1)[1]) for b in cfg["ref_bins"]]
+    if cfg["port"]:
+        candidates += [(os.path.join(port_dir, f"bench_port{s}"), "port", s.strip("_") or "scalar") for s in ("_avx512", "_avx2", "")]
 
     def run(exe, reps):
         r = subprocess.run([exe, "--reps", str(reps)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
             raise RuntimeError(f"{exe} rc={r.returncode}")
         kv = dict(line.split("=", 1) for line in r.stdout.splitlines() if "=" in line and " " not in line)
-        if int(kv["checksum"]) != REF_CHECKSUM_ROW0:
+        if int(kv["checksum"]) != cfg["checksum_row0"]:
             raise RuntimeError("baseline checksum mismatch")
         return float(kv["avg_ns"])
 
@@ -96,7 +155,7 @@ def cpu_baseline(budget_s=12.0):
         if not os.path.exists(exe):
             continue
         try:
-            probe = run(exe, 50)                                   # ~0.1 s: calibrate reps
+            probe = run(exe, 50)                                   # calibrate reps
             reps1 = max(100, int(budget_s * 0.4 * 1e9 / (probe * 1.35)))
             single_ns = run(exe, reps1)
             repsN = max(100, int(budget_s * 0.6 * 1e9 / (probe * 1.35)))
@@ -116,7 +175,7 @@ def cpu_baseline(budget_s=12.0):
                         others[k] = round(1e9 / run(e2, max(100, int(1e9 / (probe * 1.5)))), 1)
                     except Exception as e:
                         sys.stderr.write(f"[bench] {e2} skipped: {e}\n")
-            return {"value": round(allcore, 1), "unit": "poly-mults/s", "cores": cores, "kind": kind,
+            return {"value": round(allcore, 1), "unit": "poly-mults/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
                     "simd": simd, "single_thread_value": round(1e9 / single_ns, 1), "single_thread_avg_ns": round(single_ns),
                     "single_thread_other_builds": others,
                     "sample": f"{os.path.basename(exe)}: same pair make_poly(1)xmake_poly(2) every rep (reference main loop); "
@@ -126,25 +185,50 @@ def cpu_baseline(budget_s=12.0):
     return None
 
 
-def main():
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this
+    process has touched the GPU or imported torch), let rank 0 print the line, return the worst exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)     # the first launches after idle run below the steady clock
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU, weak scaling (default: see the module docstring)")
+    ap.add_argument("--global-batch", type=int, default=None, help="rows of ONE global batch split over the ranks, strong scaling")
     ap.add_argument("--variant", default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="N>1: if the RCCL control plane cannot come up, run the barrier / max-reduce over gloo instead of failing")
     ap.add_argument("--scatter-gather", type=int, default=0, metavar="ROWS",
                     help="N>1 only, off by default: also time the OPTIONAL scatter of a, b from rank 0 and gather of c "
                          "(tiny_ntt_amd.dist, point-to-point over RCCL/xGMI) on ROWS rows per rank; reported separately, never part of value")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
     from tiny_ntt_amd import dist as tdist, engine
 
+    cfg = CONFIGS[args.config]
     rank, local_rank, world = tdist.env_rank_world()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -153,47 +237,62 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    control_plane, counted = "none", 1
     if world > 1:
         if backend == "nccl":
-            # the only collectives of this job are the timing barrier and a max-reduce of two floats: if RCCL cannot
-            # come up on this node, run that control plane over gloo instead of losing the measurement
+            # the only collectives of this job are the timing barrier and a max-reduce of two floats
             try:
                 tdist.init_process_group(backend)
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe)
                 torch.cuda.synchronize(dev)
-                assert int(probe.item()) == world
+                counted = int(probe.item())
+                if counted != world:
+                    raise RuntimeError(f"RCCL all-reduce counted {counted} ranks, expected {world}")
+                control_plane = "rccl"
             except Exception as e:
-                sys.stderr.write(f"[bench] RCCL control plane unavailable ({type(e).__name__}: {str(e)[:200]}); using gloo for barrier/max-reduce\n")
+                sys.stderr.write(f"[bench] rank {rank}: RCCL control plane failed: {type(e).__name__}: {str(e)[:400]}\n")
+                if not args.allow_gloo:
+                    sys.stderr.write("[bench] not falling back silently: pass --allow-gloo (or BENCH_BACKEND=gloo) to run the "
+                                     "barrier / max-reduce over gloo\n")
+                    raise SystemExit(3)
                 try:
                     if dist.is_initialized():
                         dist.destroy_process_group()
                 except Exception:
                     pass
                 backend = "gloo"
-                tdist.init_process_group(backend)
-        else:
+        if backend != "nccl":
             tdist.init_process_group(backend)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+            probe = torch.ones(1)
+            dist.all_reduce(probe)
+            counted = int(probe.item())
+            control_plane = backend
+    red_dev = dev if control_plane == "rccl" else torch.device("cpu")
 
-    plan = engine.Plan(N_COEFF, Q, PSI, device=dev_index)
-    rows = args.rows
-    first_row = rank * rows                                    # this rank's block of the global batch
-    a = plan.fill_lcg(rows, 2 * first_row + 1, 2)              # global row r: make_poly(2r+1), make_poly(2r+2)
-    b = plan.fill_lcg(rows, 2 * first_row + 2, 2)
+    plan = engine.Plan(cfg["n"], cfg["q"], cfg["psi"], device=dev_index)
+    if plan.elem_bytes != cfg["elem_bytes"]:
+        raise SystemExit("unexpected lane width for this configuration")
+    sp = shard_plan(cfg, world, rank, args.rows, args.global_batch)
+    rows, first_row = sp["rows"], sp["first_row"]
+    bytes_per_product = 3 * cfg["n"] * cfg["elem_bytes"]
+    S = "plan"                                               # every launch, sync and HIP event of this run uses the plan's own stream
+    sa, sb, stride = seeds_for(first_row)
+    a = plan.fill_lcg(rows, sa, stride, stream=S)            # global row r: make_poly(2r+1), make_poly(2r+2)
+    b = plan.fill_lcg(rows, sb, stride, stream=S)
     c = torch.empty_like(a)
     plan.synchronize()
 
     # correctness first (one pass, checked), so that nothing idles the device between warm-up and the timed steps
-    plan.poly_mult(a, b, variant=args.variant, out=c)
+    plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
     plan.synchronize()
-    checked = verify(plan, a, b, c, first_row)
+    checked, first_sum = verify(plan, a, b, c, first_row, cfg)
     # device spin-up (part of setup, like plan creation and data generation): after idle the first ~0.1 s of launches run
-    # below the steady shader clock (profiles/: 3.6 ms against 2.7 ms), whatever W the caller asks for
+    # below the steady shader clock, whatever W the caller asks for
     for _ in range(40):
-        plan.poly_mult(a, b, variant=args.variant, out=c)
+        plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
     for _ in range(max(args.warmup, 0)):                      # the W untimed warm-up steps of the contract
-        plan.poly_mult(a, b, variant=args.variant, out=c)
+        plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
     plan.synchronize()
 
     def barrier():
@@ -205,70 +304,79 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.poly_mult(a, b, variant=args.variant, out=c)       # enqueue on the plan's stream, inputs resident in HBM
+        plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)     # enqueue on the plan's stream, inputs resident in HBM
     plan.synchronize()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed = tdist.max_over_ranks(elapsed, red_dev)
 
-    # dominant kernel: mean launch duration with HIP events on the stream it runs on
+    # dominant kernel: mean launch duration with HIP events on the plan's stream (the one the timed loop used)
     kernel_ms = plan.time_poly_mult(a, b, c, max(args.steps, 5), args.variant)
     kernel_ms = tdist.max_over_ranks(kernel_ms, red_dev)
-    achieved = rows * BYTES_PER_PRODUCT / (kernel_ms * 1e-3) / 1e9
+    max_rows = int(tdist.max_over_ranks(rows, red_dev))        # the rank that sets the time owns the largest block
+    achieved = max_rows * bytes_per_product / (kernel_ms * 1e-3) / 1e9
+
+    # the timed launches must have left the checked result in place
+    _, last_sum = verify(plan, a, b, c, first_row, cfg)
+    parity_ok = last_sum == first_sum
 
     sg = None
     if args.scatter_gather > 0 and world > 1:
         # optional data-movement leg: the compute path above never needs it
         r_sg = min(args.scatter_gather, rows)
-        stage = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
-        back = (lambda t: t) if backend == "nccl" else (lambda t: t.to(dev))
+        on_dev = control_plane == "rccl"
+        stage = (lambda t: t) if on_dev else (lambda t: t.cpu())
+        back = (lambda t: t) if on_dev else (lambda t: t.to(dev))
         full_a = stage(plan.fill_lcg(r_sg * world, 1, 2)) if rank == 0 else None
         full_b = stage(plan.fill_lcg(r_sg * world, 2, 2)) if rank == 0 else None
-        sdev = dev if backend == "nccl" else torch.device("cpu")
+        sdev = dev if on_dev else torch.device("cpu")
         barrier()
         t1 = time.perf_counter()
-        my_a = tdist.scatter_rows(full_a, r_sg * world, N_COEFF, a.dtype, sdev)
-        my_b = tdist.scatter_rows(full_b, r_sg * world, N_COEFF, a.dtype, sdev)
+        my_a = tdist.scatter_rows(full_a, r_sg * world, cfg["n"], a.dtype, sdev)
+        my_b = tdist.scatter_rows(full_b, r_sg * world, cfg["n"], a.dtype, sdev)
         torch.cuda.synchronize(dev); barrier()
         t_sc = tdist.max_over_ranks(time.perf_counter() - t1, red_dev)
         my_c = plan.poly_mult(back(my_a), back(my_b), variant=args.variant)
-        plan.synchronize()
+        torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
-        full_c = tdist.gather_rows(stage(my_c), r_sg * world, N_COEFF)
+        full_c = tdist.gather_rows(stage(my_c), r_sg * world, cfg["n"])
         torch.cuda.synchronize(dev); barrier()
         t_ga = tdist.max_over_ranks(time.perf_counter() - t2, red_dev)
         ok = True
         if rank == 0:
             ref_c = plan.poly_mult(back(full_a), back(full_b), variant=args.variant)
-            plan.synchronize()
+            torch.cuda.synchronize(dev)
             ok = bool(torch.equal(back(full_c), ref_c))
-        row_bytes = N_COEFF * 8
+        row_bytes = cfg["n"] * cfg["elem_bytes"]
         sg = {"rows_per_rank": r_sg, "scatter_ms": round(t_sc * 1e3, 3), "gather_ms": round(t_ga * 1e3, 3),
               "scatter_GBps": round(2 * r_sg * (world - 1) * row_bytes / t_sc / 1e9, 1),
               "gather_GBps": round(r_sg * (world - 1) * row_bytes / t_ga / 1e9, 1), "gathered_product_bit_exact": ok,
-              "transport": "RCCL point-to-point" if backend == "nccl" else "gloo (host staging)"}
+              "transport": "RCCL point-to-point" if on_dev else "gloo (host staging)"}
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")   # HBM bytes per launch from separate rocprofv3 --pmc passes
+    # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/gpu_pmc.sh): only if taken on THIS library build
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("rows") == rows and tj.get("kernel") == plan.kernel_name(args.variant):
+            if tj.get("lib_build_id") != engine.build_id():
+                traffic_note = f"profiles/traffic_latest.json belongs to build {tj.get('lib_build_id')}, this library is {engine.build_id()}: not reported"
+            elif tj.get("rows") == max_rows and tj.get("kernel") == plan.kernel_name(args.variant) and tj.get("config", "cfg3") == args.config:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
-    total = rows * world * args.steps
+    total = sp["global_batch"] * args.steps
     value = total / elapsed
     if rank == 0:
         base, oracle_rows = None, 0
         if not (args.no_cpu_baseline or world > 1):          # the CPU leg: oracle as checker, reference binary as baseline
-            oracle_rows = oracle_check(plan, a, b, c)
-            base = cpu_baseline()
+            oracle_rows = oracle_check(plan, a, b, c, cfg)
+            base = cpu_baseline(cfg)
         line = {
-            "metric": "negacyclic poly-mults/sec (n=4096, 60-bit q), bit-exact vs cg_ntt.py",
+            "metric": cfg["metric"],
             "value": round(value, 1),
             "unit": "poly-mults/s",
             "n_gpus": world,
@@ -276,23 +384,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": sp["scaling"],
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": cfg["dtype"],
             "data": "synthetic",
-            "config": {"workload": f"n=4096, q=2^60-2^14+1 (60-bit), batch={rows} per GPU, LCG-seeded rows resident in HBM (BASELINE configs[2])",
-                       "n": N_COEFF, "q": Q, "rows_per_gpu": rows, "global_batch": rows * world,
+            "config": {"workload": f"{cfg['label']}, global batch {sp['global_batch']} = {rows} rows on this GPU"
+                                   f"{'' if world == 1 else ' (contiguous row blocks, rows_g = batch/N)'}, LCG-seeded rows resident in HBM "
+                                   f"({cfg['baseline_cfg'] if world == 1 else 'BASELINE configs[3]' if args.config == 'cfg3' and sp['scaling'] == 'strong' else cfg['baseline_cfg'] + ' per GPU'})",
+                       "name": args.config, "n": cfg["n"], "q": cfg["q"], "rows_per_gpu": max_rows, "global_batch": sp["global_batch"],
                        "variant": args.variant, "kernel": plan.kernel_name(args.variant), "lazy_reduction": plan.is_lazy,
+                       "lib_build_id": engine.build_id(),
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "ntts_per_s": round(3 * value, 1),
-            "parity": {"row0_checksum": REF_CHECKSUM_ROW0, "rows_compared_with_direct_product_on_device": checked,
-                       "rows_compared_with_cpu_oracle": oracle_rows, "bit_exact": True},
+            "control_plane": control_plane,
+            "control_plane_ranks": counted,
+            "parity": {"first_row_checksum_device": first_sum, "reference_row0_checksum": cfg["checksum_row0"],
+                       "row0_matches_reference": (first_sum == cfg["checksum_row0"]) if first_row == 0 else None,
+                       "rows_compared_with_direct_product_on_device": checked,
+                       "rows_compared_with_cpu_oracle": oracle_rows,
+                       "bit_exact": bool(parity_ok and (first_row != 0 or first_sum == cfg["checksum_row0"]))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": plan.kernel_name(args.variant), "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": rows * BYTES_PER_PRODUCT},
+                         "algorithmic_bytes_per_launch": max_rows * bytes_per_product},
             "cpu_baseline": base,
         }
+        if traffic_note:
+            line["roofline"]["traffic_note"] = traffic_note
         if sg is not None:
             line["scatter_gather"] = sg
         print(json.dumps(line), flush=True)

@@ -190,6 +190,9 @@ const char *tn_kernel_name(const tn_plan *plan, tn_variant variant);
 const char *tn_last_error(void);
 const char *tn_status_string(tn_status s);
 int tn_version(void);
+/* First 16 hex digits of the sha256 of the sources this library was built from (csrc/Makefile); lets a stored
+ * measurement (profiles/traffic_latest.json) say which build it was taken on.  No counterpart in the reference. */
+const char *tn_build_id(void);
 
 #ifdef __cplusplus
 }

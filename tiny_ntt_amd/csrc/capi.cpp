@@ -38,6 +38,10 @@ struct DeviceGuard {
 
 extern "C" const char* tn_last_error(void) { return g_err.c_str(); }
 extern "C" int tn_version(void) { return TN_VERSION; }
+#ifndef TN_BUILD_ID
+#define TN_BUILD_ID "unknown"
+#endif
+extern "C" const char* tn_build_id(void) { return TN_BUILD_ID; }
 extern "C" const char* tn_status_string(tn_status s) {
   switch (s) {
     case TN_OK: return "ok";

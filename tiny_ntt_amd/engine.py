@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
     "tn_ntt_forward_host", "tn_ntt_inverse_host", "tn_ntt_forward_trace_host", "tn_twisted_ntt_forward_dev",
     "tn_fill_lcg_dev", "tn_checksum_rows_dev", "tn_plan_synchronize", "tn_time_poly_mult_dev",
-    "tn_kernel_name", "tn_last_error", "tn_status_string", "tn_version",
+    "tn_kernel_name", "tn_last_error", "tn_status_string", "tn_version", "tn_build_id",
 )
 
 
@@ -97,9 +97,15 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.tn_status_string.argtypes = [ci]
     lib.tn_status_string.restype = ctypes.c_char_p
     lib.tn_version.restype = ci
+    lib.tn_build_id.restype = ctypes.c_char_p
     if path is None:
         _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """sha256 prefix of the sources the loaded libtinyntt.so was compiled from (tn_build_id)."""
+    return load_library().tn_build_id().decode()
 
 
 def _check(lib, status: int):
