@@ -60,7 +60,17 @@ typedef enum tn_variant {
   TN_VARIANT_FUSED = 1, /* register/LDS-tiled merged-twiddle kernel (the throughput path) */
   TN_VARIANT_CG = 2,    /* constant-geometry stage sweep in LDS: the dataflow of cg_ntt.py:49-64 */
   TN_VARIANT_CG8 = 3,   /* same, butterflies issued 8 per lane-step: cg_ntt_8butterfly.py:61-89 */
-  TN_VARIANT_CG8_PADDED = 4 /* CG8 with the padded (bank-conflict-free) LDS image; for the rocprof sweep */
+  TN_VARIANT_CG8_PADDED = 4, /* CG8 with 16 bytes of padding per lane-step in the LDS image; for the rocprof sweep */
+  /* the rest of the lane-grouping x LDS-layout sweep (BASELINE config 5): GROUP butterflies per lane-step in {1, 2, 4, 8},
+   * layout in {linear, padded, swizzled}; SWIZZLED = XOR-swizzled image, bank-conflict free for every access of the sweep */
+  TN_VARIANT_CG_SWIZZLED = 5,
+  TN_VARIANT_CG8_SWIZZLED = 6,
+  TN_VARIANT_CG2 = 7,
+  TN_VARIANT_CG2_PADDED = 8,
+  TN_VARIANT_CG2_SWIZZLED = 9,
+  TN_VARIANT_CG4 = 10,
+  TN_VARIANT_CG4_PADDED = 11,
+  TN_VARIANT_CG4_SWIZZLED = 12
 } tn_variant;
 
 typedef struct tn_plan tn_plan;

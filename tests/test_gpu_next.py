@@ -32,7 +32,7 @@ def test_cyclic_product_matches_rtl_reference_model(eng, oracle, tag):
     rng = np.random.default_rng(99)
     a = rng.integers(0, q, (3, n), dtype=np.uint64); b = rng.integers(0, q, (3, n), dtype=np.uint64)
     a[0] = 0; a[0, :3] = [1, 2, 3]; b[0] = 0; b[0, :2] = [5, 1]                      # chipyard/ntt-test.c KAT
-    for v in ("cg", "cg8", "cg8_padded") + (("fused", "auto") if plan.has_fused else ()):
+    for v in ("cg", "cg8", "cg8_padded", "cg_swizzled", "cg4_swizzled", "cg2_padded") + (("fused", "auto") if plan.has_fused else ()):
         got = plan.cyclic_poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
         for r in range(3):
             assert np.array_equal(got[r], cyclic_oracle(oracle, a[r], b[r], q, plan.omega)), (tag, v, r)

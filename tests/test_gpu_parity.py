@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 TAGS = ["P4", "P256", "P1024", "P4096", "P4096_60"]
 ALL_VARIANTS = ["fused", "cg", "cg8", "cg8_padded"]
+# the whole lane-grouping x LDS-layout sweep of the constant-geometry kernel (BASELINE config 5): identical bits everywhere
+CG_SWEEP = ["cg", "cg_swizzled", "cg2", "cg2_padded", "cg2_swizzled", "cg4", "cg4_padded", "cg4_swizzled", "cg8", "cg8_padded", "cg8_swizzled"]
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +68,7 @@ def test_transforms_and_stage_traces_match_reference_golden(eng, golden, tag):
         for v in ("auto", "fused") if plan.has_fused else ():
             assert np.array_equal(plan.ntt_forward(x.astype(plan.dtype), variant=v).astype(np.uint64), X), f"{name} {v}"
             assert np.array_equal(plan.ntt_inverse(X.astype(plan.dtype), variant=v).astype(np.uint64), x % np.uint64(g.q)), f"{name} {v} inverse"
-        for v in ("cg", "cg8", "cg8_padded"):
+        for v in CG_SWEEP:
             assert np.array_equal(plan.ntt_forward(x.astype(plan.dtype), variant=v).astype(np.uint64), X), f"{name} {v}"
             assert np.array_equal(plan.ntt_inverse(X.astype(plan.dtype), variant=v).astype(np.uint64), x % np.uint64(g.q)), f"{name} {v} inverse"
             out, trace = plan.ntt_forward_trace(x.astype(plan.dtype), variant=v)
@@ -92,7 +94,7 @@ def test_random_batches_vs_oracle_incl_unreduced_inputs(eng, oracle, tag):
     a[2], b[2] = word, word
     a[3] = 0
     ref = oracle.poly_mult(a, b, q, psi)
-    for v in variants_of(plan):
+    for v in variants_of(plan) + CG_SWEEP:
         got = plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64)
         assert np.array_equal(got, ref), f"{tag} {v}: {np.count_nonzero(got != ref)} coefficients differ"
     for v in (["fused"] if plan.has_fused else []) + ["cg"]:
@@ -333,7 +335,7 @@ def _full_size_properties(eng, oracle, tag, batch, check_rows):
     # EVERY row of the batch: the fused (persistent, register-tiled) kernel equals the constant-geometry kernel,
     # a different dataflow with canonical arithmetic; the grouped variants on a slab
     assert torch.equal(plan.poly_mult(a, b, variant="cg"), c)
-    for v in ("cg8", "cg8_padded"):
+    for v in CG_SWEEP[1:]:
         assert torch.equal(plan.poly_mult(a[:512], b[:512], variant=v), c[:512]), v
     # outputs canonical
     assert int(plan.to_host(c).max()) < q

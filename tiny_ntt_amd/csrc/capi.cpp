@@ -56,8 +56,8 @@ extern "C" const char* tn_status_string(tn_status s) {
   return "unknown";
 }
 
-// Upload a table of constants as Tw32[] or Tw64[]: Shoup records (value + Barrett quotient factor), or for the
-// fused kernels' tables (fused = true) whatever h_make_fused_tw picks for this plan (split constants when lazy, 64-bit).
+// Upload a table of constants as Tw32[] or Tw64[]: the record format h_make_fused_tw picks for this plan (split constants
+// when lazy with 64-bit lanes, Shoup records = value + Barrett quotient factor otherwise); fused = false forces Shoup.
 static hipError_t upload_tw(const std::vector<u64>& vals, const HostTables& t, bool fused, void** dptr) {
   hipError_t e;
   if (t.elem_bytes == 8) {
@@ -103,7 +103,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   const HostTables t = h_build_tables(n, q, psi, !(flags & TN_PLAN_FORCE_CANONICAL));
   p->n = n; p->logn = logn; p->q = q; p->psi = psi; p->omega = t.omega;
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
-  p->k = t.k; p->lazy = t.lazy;
+  p->k = t.k; p->lazy = t.lazy; p->cg_lazy = t.cg_lazy;
   if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
   p->has_fused = fused_supported(logn, elem_bytes);
   {
@@ -114,11 +114,11 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = upload_tw(t.psi_brv, t, true, &p->d_psi_brv);
   if (e == hipSuccess) e = upload_tw(t.psi_inv_brv, t, true, &p->d_psi_inv_brv);
-  if (e == hipSuccess) e = upload_tw(t.omega_pow, t, false, &p->d_omega_pow);
-  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, false, &p->d_omega_inv_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_pow, t, false, &p->d_psi_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, t, false, &p->d_psi_inv_ninv);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, t, false, &p->d_psi_inv_pow);
+  if (e == hipSuccess) e = upload_tw(t.omega_pow, t, true, &p->d_omega_pow);
+  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, true, &p->d_omega_inv_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_pow, t, true, &p->d_psi_pow);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, t, true, &p->d_psi_inv_ninv);
+  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, t, true, &p->d_psi_inv_pow);
   if (e == hipSuccess) e = upload_tw(t.cyc_brv, t, true, &p->d_cyc_brv);
   if (e == hipSuccess) e = upload_tw(t.cyc_inv_brv, t, true, &p->d_cyc_inv_brv);
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_sched, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
@@ -161,12 +161,20 @@ extern "C" int tn_plan_is_lazy(const tn_plan* p) { return p && p->lazy; }
 
 static hipStream_t pick_stream(tn_plan* p, void* stream) { return stream ? (hipStream_t)stream : p->stream; }
 
-struct CgSel { int group; bool padded; };
+struct CgSel { int group; int layout; };     // layout: kernels.hip CgLayout (0 linear, 1 padded, 2 swizzled)
 static bool cg_sel(tn_variant v, CgSel* s) {
   switch (v) {
-    case TN_VARIANT_CG: *s = {1, false}; return true;
-    case TN_VARIANT_CG8: *s = {8, false}; return true;
-    case TN_VARIANT_CG8_PADDED: *s = {8, true}; return true;
+    case TN_VARIANT_CG: *s = {1, 0}; return true;
+    case TN_VARIANT_CG8: *s = {8, 0}; return true;
+    case TN_VARIANT_CG8_PADDED: *s = {8, 1}; return true;
+    case TN_VARIANT_CG_SWIZZLED: *s = {1, 2}; return true;
+    case TN_VARIANT_CG8_SWIZZLED: *s = {8, 2}; return true;
+    case TN_VARIANT_CG2: *s = {2, 0}; return true;
+    case TN_VARIANT_CG2_PADDED: *s = {2, 1}; return true;
+    case TN_VARIANT_CG2_SWIZZLED: *s = {2, 2}; return true;
+    case TN_VARIANT_CG4: *s = {4, 0}; return true;
+    case TN_VARIANT_CG4_PADDED: *s = {4, 1}; return true;
+    case TN_VARIANT_CG4_SWIZZLED: *s = {4, 2}; return true;
     default: return false;
   }
 }
@@ -193,7 +201,7 @@ extern "C" tn_status tn_poly_mult_dev(tn_plan* p, const void* a, const void* b, 
   }
   CgSel sel;
   if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, "unknown variant");
-  TN_HIP(launch_cg(p, CG_POLYMUL, sel.group, sel.padded, a, b, c, nullptr, batch, s));
+  TN_HIP(launch_cg(p, CG_POLYMUL, sel.group, sel.layout, a, b, c, nullptr, batch, s));
   return TN_OK;
 }
 
@@ -210,7 +218,7 @@ extern "C" tn_status tn_cyclic_poly_mult_dev(tn_plan* p, const void* a, const vo
   }
   CgSel sel;
   if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, "tn_cyclic_poly_mult_dev: unknown variant");
-  TN_HIP(launch_cg(p, CG_CYCLIC_POLYMUL, sel.group, sel.padded, a, b, c, nullptr, batch, pick_stream(p, stream)));
+  TN_HIP(launch_cg(p, CG_CYCLIC_POLYMUL, sel.group, sel.layout, a, b, c, nullptr, batch, pick_stream(p, stream)));
   return TN_OK;
 }
 
@@ -237,12 +245,12 @@ extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out)
   if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
   TN_ON_DEVICE(p);
-  // device records are {w, w'} pairs (or, tables 4 and 5 of a lazy 64-bit plan, split constants); only the
-  // constants w are exported, as uint64
+  // device records are {w, w'} pairs (or, in a lazy 64-bit plan, split constants); only the constants w are
+  // exported, as uint64
   std::vector<unsigned char> raw(count * 2 * (size_t)p->elem_bytes);
   TN_HIP(hipMemcpy(raw.data(), tabs[which], raw.size(), hipMemcpyDeviceToHost));
   uint64_t* out = (uint64_t*)host_out;
-  const bool split = p->lazy && p->elem_bytes == 8 && (which == 4 || which == 5);
+  const bool split = p->lazy && p->elem_bytes == 8;
   for (size_t i = 0; i < count; ++i) {
     if (p->elem_bytes == 8) out[i] = split ? h_split_value(((const Tw64*)raw.data())[i], p->k) : ((const Tw64*)raw.data())[i].w;
     else out[i] = ((const Tw32*)raw.data())[i].w;
@@ -266,7 +274,7 @@ static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t
   }
   CgSel sel;
   if (!cg_sel(variant, &sel)) return fail(TN_EINVAL, std::string(fn) + ": unknown variant");
-  TN_HIP(launch_cg(p, mode, sel.group, sel.padded, in, nullptr, out, trace, batch, pick_stream(p, stream)));
+  TN_HIP(launch_cg(p, mode, sel.group, sel.layout, in, nullptr, out, trace, batch, pick_stream(p, stream)));
   return TN_OK;
 }
 
@@ -467,6 +475,6 @@ extern "C" const char* tn_kernel_name(const tn_plan* p, tn_variant variant) {
   if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
   if (variant == TN_VARIANT_FUSED) return fused_kernel_name(p);
   CgSel sel;
-  if (cg_sel(variant, &sel)) return cg_kernel_name(p, sel.group, sel.padded);
+  if (cg_sel(variant, &sel)) return cg_kernel_name(p, sel.group, sel.layout);
   return "";
 }

@@ -13,7 +13,7 @@ struct tn_plan {
   int num_cus = 256;
   tn::u32 flags = 0;
   int elem_bytes = 8;
-  bool has_fused = false, lazy = false;
+  bool has_fused = false, lazy = false, cg_lazy = false;
   int k = 0;            // bitlen(q)
   tn::Arith<tn::u64> ar64 = {};    // kernel-argument constants (h_make_arith); the one matching elem_bytes is used
   tn::Arith<tn::u32> ar32 = {};
@@ -25,9 +25,9 @@ struct tn_plan {
   hipStream_t copy_in = nullptr, copy_out = nullptr;
   hipEvent_t ev_in[HOST_SLOTS] = {}, ev_k[HOST_SLOTS] = {}, ev_out[HOST_SLOTS] = {};
   size_t host_chunk_rows = 0;      // rows per chunk; 0 = automatic (HOST_CHUNK_BYTES per operand)
-  // device tables (Tw32[] or Tw64[] according to elem_bytes).  The four tables of the fused kernels (psi_brv, psi_inv_brv,
-  // cyc_brv, cyc_inv_brv) hold split-constant records when the plan is lazy with 64-bit lanes (h_make_fused_tw), every
-  // other table Shoup records {w, floor(w 2^W / q)}.
+  // device tables (Tw32[] or Tw64[] according to elem_bytes): split-constant records when the plan is lazy with 64-bit
+  // lanes (h_make_fused_tw; the constant-geometry kernels then run their SPLIT instantiation), Shoup records
+  // {w, floor(w 2^W / q)} otherwise.
   void* d_psi_brv = nullptr;       // [n]   psi^brv(i): merged forward twiddles (fused kernel)
   void* d_psi_inv_brv = nullptr;   // [n]   psi^-brv(i)
   void* d_omega_pow = nullptr;     // [n/2] omega^j   (cg_ntt.py:51,54 — pow(omega_s, i//k) = omega^(k*(i//k)))
@@ -86,10 +86,10 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
 // kernels.hip
 bool fused_supported(u32 logn, int elem_bytes);
 const char* fused_kernel_name(const tn_plan* p);
-const char* cg_kernel_name(const tn_plan* p, int group, bool padded);
+const char* cg_kernel_name(const tn_plan* p, int group, int layout);
 hipError_t launch_polymul_fused(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s, bool cyclic = false);
 hipError_t launch_ntt_fused(const tn_plan* p, int mode, const void* in, void* out, size_t batch, hipStream_t s);
-hipError_t launch_cg(const tn_plan* p, int mode, int group, bool padded, const void* a, const void* b, void* out,
+hipError_t launch_cg(const tn_plan* p, int mode, int group, int layout, const void* a, const void* b, void* out,
                      void* trace, size_t batch, hipStream_t s);
 hipError_t launch_pointwise(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);
 hipError_t launch_schoolbook(const tn_plan* p, const void* a, const void* b, void* c, size_t batch, hipStream_t s);

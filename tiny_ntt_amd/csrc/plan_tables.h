@@ -11,6 +11,7 @@ struct HostTables {
   u64 q = 0, psi = 0, omega = 0, mu = 0;
   int k = 0, elem_bytes = 8;
   bool lazy = false;
+  bool cg_lazy = false;      // lazy, 64-bit lanes, and the constant-geometry kernels may run lazy butterflies (h_cg_lazy_ok)
   u32 fold_c = 0;
   u64 n_inv = 0, ninv_w1 = 0;
   std::vector<u64> psi_pow, psi_inv_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
@@ -146,6 +147,23 @@ template <typename Cfg> inline bool h_split_sched_replay(int k, u64 c) {
   return x.ok;
 }
 
+// Lazy butterflies of the constant-geometry kernels (cg_butterfly_lazy in kernels.hip): left folded, product riding,
+// difference 2 left + 6q - x; every stage input below B = fold bound + 6q.  Exact replay for (k, c).
+inline bool h_cg_lazy_ok(int k, u64 c) {
+  typedef unsigned __int128 u128;
+  SplitExact x(k, c);
+  if (!x.ok) return false;
+  const u128 bu = x.folded(x.two64);                // fold() of any word
+  const u128 kq = (u128)6 * x.q;
+  const u128 B = bu + kq;                           // bound of the difference output; the sum output must stay below it too
+  const u128 t = x.tmax(B);
+  if (kq + 1 < t) x.ok = false;                     // 6q >= t'max
+  x.fits(bu - 1 + t); x.fits(B);
+  if (bu + t - 1 > B) x.ok = false;
+  if (x.folded(B) > (u128)2 * x.q) x.ok = false;    // canonicalisation afterwards: fold, one conditional subtraction
+  return x.ok;
+}
+
 // Is the split-constant lazy policy valid for this (n, k, c)?  (false too when no fused kernel is built for n)
 inline bool h_split_sched_ok(u32 logn, int k, u64 c) {
   switch (logn) {
@@ -171,6 +189,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   if (t.lazy && t.elem_bytes == 8 && !h_pw_fast_ok(q, t.k, t.fold_c)) t.lazy = false;     // 64-bit lazy pointwise product needs it
   if (t.lazy && t.elem_bytes == 8 && !h_split_sched_ok(logn, t.k, t.fold_c)) t.lazy = false;   // ... and the butterflies this
   if (!t.lazy) t.fold_c = 0;
+  t.cg_lazy = t.lazy && t.elem_bytes == 8 && h_cg_lazy_ok(t.k, t.fold_c);
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72
   t.n_inv = h_powmod(n % q, q - 2, q);                          // :74

@@ -26,7 +26,10 @@ LIB_PATH = os.environ.get("TINYNTT_LIB") or os.path.join(_HERE, "lib", "libtinyn
 TN_OK, TN_EBADLEN, TN_EBADPARAM, TN_ENODEVICE, TN_EHIP, TN_ENOMEM, TN_EINVAL, TN_EUNSUPPORTED = range(8)
 # tn_variant
 VARIANT_AUTO, VARIANT_FUSED, VARIANT_CG, VARIANT_CG8, VARIANT_CG8_PADDED = range(5)
-VARIANTS = {"auto": VARIANT_AUTO, "fused": VARIANT_FUSED, "cg": VARIANT_CG, "cg8": VARIANT_CG8, "cg8_padded": VARIANT_CG8_PADDED}
+VARIANTS = {"auto": VARIANT_AUTO, "fused": VARIANT_FUSED, "cg": VARIANT_CG, "cg8": VARIANT_CG8, "cg8_padded": VARIANT_CG8_PADDED,
+            # lane-grouping x LDS-layout sweep of the constant-geometry kernel (BASELINE config 5)
+            "cg_swizzled": 5, "cg8_swizzled": 6, "cg2": 7, "cg2_padded": 8, "cg2_swizzled": 9, "cg4": 10, "cg4_padded": 11, "cg4_swizzled": 12}
+CG_VARIANTS = tuple(k for k in VARIANTS if k.startswith("cg"))
 PLAN_FORCE_CANONICAL = 1
 
 # Every symbol include/tinyntt.h declares (tests check the built library exports them all).
