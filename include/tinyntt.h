@@ -87,6 +87,15 @@ typedef struct tn_plan tn_plan;
  * Validates n = 2^m (4 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q).
  */
 tn_status tn_plan_create(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags);
+/*
+ * Plan for the UNTWISTED transforms with an arbitrary omega_n: cg_ntt(a_prime, omega_n, modulus) and
+ * cg_intt(A, omega_n, modulus) (cg_ntt.py:29-75) evaluate their butterflies for ANY omega_n — it need not be a primitive
+ * n-th root, nor have a square root psi mod q; the inverse uses modinv(omega_n) = omega_n^(q-2) (:72) and n^-1 (:74).
+ * Such a plan offers tn_ntt_forward_* / tn_ntt_inverse_* / tn_ntt_forward_trace_host with the constant-geometry variants
+ * (plus tn_pointwise_mul_dev, tn_fill_lcg_dev, tn_checksum_rows_dev); everything that needs psi returns TN_EUNSUPPORTED.
+ * q: odd prime < 2^62 (the reference takes any modulus; non-prime moduli are not supported here).
+ */
+tn_status tn_plan_create_omega(tn_plan **out, uint32_t n, uint64_t q, uint64_t omega, int device, uint32_t flags);
 tn_status tn_plan_destroy(tn_plan *plan);
 
 uint32_t tn_plan_n(const tn_plan *plan);

@@ -178,7 +178,55 @@ def hex_digests():
     print("hex digests:", len(out))
 
 
+def find_psi_outputs():
+    """What the reference's parameter finder returns (scripts/find_psi.py:9-43, imported, stdout discarded) for the
+    parameter sets of this repo, its own three demo sets (:60-64) and a search bound that excludes the answer."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    import find_psi as ref_find      # noqa: E402
+    cases = [(n, q, 10000) for (n, q, _psi) in PARAMS.values() if n >= 256]
+    cases += [(256, 7681, 10000), (512, 12289, 10000), (1024, 8380417, 100), (256, 8380417, 1754), (256, 8380417, 1753)]
+    out = []
+    for n, q, bound in cases:
+        with contextlib.redirect_stdout(io.StringIO()):
+            psi = ref_find.find_psi(n, q, bound)
+        out.append({"n": n, "q": q, "max_search": bound, "psi": psi})
+    with open(os.path.join(HERE, "reference_find_psi.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("find_psi cases:", out)
+
+
+def general_omega_cases():
+    """cg_ntt / cg_intt accept ANY omega_n (cg_ntt.py:29-65 only evaluates the butterflies): outputs of the reference for
+    omegas that are not primitive n-th roots (a non-root, a root of lower order, 0, 1) and one that is, at n = 256 and
+    n = 4096 / 60-bit; and a modulus where 2n does not divide q - 1 (omega has no square root psi)."""
+    arrays, meta = {}, []
+    rng = random.Random(2024)
+    sets = [(256, 8380417, [3, 1239911 ** 4 % 8380417, 0, 1, 1239911 ** 2 % 8380417]),
+            (4096, 1152921504606830593, [5, 1, pow(431606828070683274, 2, 1152921504606830593)]),
+            (16, 97, [8, 5])]                     # q = 97: 2n = 32 | 96; omega = 8 has order 16 ... and 5 is a non-residue
+    for n, q, omegas in sets:
+        set_params(n, q)
+        x = [rng.randrange(q) for _ in range(n)]
+        for w in omegas:
+            name = f"n{n}_q{q}_w{w}"
+            X = ref.cg_ntt(list(x), w, q)
+            arrays[name + "_x"], arrays[name + "_X"] = u64(x), u64(X)
+            entry = {"name": name, "n": n, "q": q, "omega": w}
+            if w % q and pow(w, q - 1, q) == 1:
+                arrays[name + "_inv"] = u64(ref.cg_intt(list(X), w, q))       # cg_intt(cg_ntt(x)) (= x only for primitive roots)
+                entry["has_inverse"] = True
+            meta.append(entry)
+    np.savez_compressed(os.path.join(HERE, "golden_general_omega.npz"), **arrays)
+    with open(os.path.join(HERE, "golden_general_omega.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("general omega cases:", len(meta))
+
+
 if __name__ == "__main__":
     for tag in PARAMS:
         gen(tag)
     hex_digests()
+    find_psi_outputs()
+    general_omega_cases()

@@ -144,7 +144,7 @@ def test_fold_bounds(emu):
 def test_fused_emulation_other_sizes(emu, oracle, n, q):
     """n = 512 / 2048 (8 coefficients per thread, partial last phase): psi found for each (n, q)."""
     from tiny_ntt_amd import numtheory
-    psi = numtheory.find_psi(n, q)
+    psi = numtheory.primitive_2n_root(n, q)
     rng = np.random.default_rng(n)
     a = rng.integers(0, q, (4, n), dtype=np.uint64); b = rng.integers(0, q, (4, n), dtype=np.uint64)
     a[0], b[0] = q - 1, q - 1
@@ -174,7 +174,7 @@ def test_fused_emulation_modulus_sweep(emu, oracle, n):
     for k in (20, 26, 31, 32, 33, 36, 41, 47, 52, 57, 60, 61, 62):
         for limit in (2 ** k, int(0.71 * 2 ** k)):
             q = ntt_prime_below(limit, n)
-            psi = numtheory.find_psi(n, q)
+            psi = numtheory.primitive_2n_root(n, q)
             if emu.lib.emu_is_lazy(n, q, psi) == 1:
                 lazy.add(q.bit_length())
             rng = np.random.default_rng(k)
@@ -214,7 +214,7 @@ def test_fused_cyclic_product_emulation(emu, oracle, tag, canonical):
 def test_fused_standalone_transforms_other_sizes(emu, oracle, n):
     from tiny_ntt_amd import numtheory
     for q in (8380417, 1152921504606830593):
-        psi = numtheory.find_psi(n, q)
+        psi = numtheory.primitive_2n_root(n, q)
         omega = psi * psi % q
         rng = np.random.default_rng(n)
         word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1

@@ -126,9 +126,16 @@ def test_rocc_session_protocol(eng, oracle, mode):
     # debug memories expose the forward transforms of A and B (funct 5/6)
     A = oracle.cg_ntt(np.array(a + [0] * (n - 3), dtype=np.uint64), psi * psi % q, q)
     assert [s.rocc(rocc.FUNCT_DEBUG_READ_A, i) for i in (0, 1, 777, n - 1)] == [int(A[i]) for i in (0, 1, 777, n - 1)]
-    # addresses wrap to addrWidth bits, data to the coefficient width, unknown funct answers 0
+    # addresses wrap to addrWidth bits; data is TRUNCATED to the 32-bit coefficient width and stored unreduced
+    # (load_data := rs2(nttWidth-1, 0), NttRocc.scala:187, nttWidth = 32 :95); unknown funct answers 0
     s.rocc(rocc.FUNCT_LOAD_A, n + 1, q + 7)
-    assert s._a[1] == 7 and s.rocc(99, 1, 2) == 0
+    assert s.width == 32 and s._a[1] == q + 7 and s.rocc(99, 1, 2) == 0
+    s.rocc(rocc.FUNCT_LOAD_A, 2, (5 << 32) | 9)
+    assert s._a[2] == 9
+    s.rocc(rocc.FUNCT_LOAD_A, 1, 0); s.rocc(rocc.FUNCT_LOAD_A, 2, 0)
+    # an unreduced stored word is taken mod q when used: (q + 3) * x^0 times b == 3 b
+    s2 = rocc.NttRoccSession(n, q, psi, mode=mode)
+    assert s2.multiply([q + 3], [1, 1])[:3] == [3, 3, 0]
     rng = np.random.default_rng(3)
     ra = rng.integers(0, q, n, dtype=np.uint64); rb = rng.integers(0, q, n, dtype=np.uint64)
     got = np.array(s.multiply(ra, rb), dtype=np.uint64)
@@ -165,3 +172,38 @@ def test_benchmark_cli_twin_reports_like_the_reference_binary():
     got = kv(r.stdout)
     assert int(got["forward_ntt_checksum"]) == REF_CHECKSUMS["P4096"][0] and int(got["checksum"]) == REF_CHECKSUMS["P4096"][1]
     assert subprocess.run([exe, "--bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 2
+
+
+def test_omega_only_plans_follow_the_reference_for_any_omega(eng):
+    """cg_ntt / cg_intt of the reference evaluate their butterflies for ANY omega_n (cg_ntt.py:29-75): outputs generated by
+    importing the reference (tests/golden/make_golden.py: general_omega_cases) for non-roots, roots of lower order, 0, 1,
+    and an omega without a square root psi; mirrored here through the omega-only plans (tn_plan_create_omega)."""
+    import json
+    import tiny_ntt_amd.cg_ntt as cg
+    import tiny_ntt_amd.cg_ntt_8butterfly as cg8
+    from conftest import GOLDEN as GOLDEN_DIR
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "golden_general_omega.json")))
+    arrs = np.load(os.path.join(GOLDEN_DIR, "golden_general_omega.npz"))
+    oldN, oldQ = cg.N, cg.Q
+    try:
+        for m in meta:
+            cg.N, cg.Q = m["n"], m["q"]
+            x = [int(v) for v in arrs[m["name"] + "_x"]]
+            X = [int(v) for v in arrs[m["name"] + "_X"]]
+            assert cg.cg_ntt(x, m["omega"], m["q"]) == X, m
+            assert cg8.cg_ntt_8butterfly(x, m["omega"], m["q"]) == X, m
+            if m.get("has_inverse"):
+                inv = [int(v) for v in arrs[m["name"] + "_inv"]]
+                assert cg.cg_intt(X, m["omega"], m["q"]) == inv, m
+                assert cg8.cg_intt_8butterfly(X, m["omega"], m["q"]) == inv, m
+    finally:
+        cg.N, cg.Q = oldN, oldQ
+    # what an omega-only plan refuses
+    plan = eng.get_omega_plan(256, 8380417, 3)
+    assert plan.omega_only and not plan.has_fused and plan.omega == 3
+    z = np.zeros((1, 256), dtype=plan.dtype)
+    for call in (lambda: plan.poly_mult(z, z), lambda: plan.cyclic_poly_mult(z, z), lambda: plan.twisted_ntt_forward(z),
+                 lambda: plan.ntt_forward(z, variant="fused"), lambda: plan.export_table("psi_pow")):
+        with pytest.raises(eng.TinyNttError):
+            call()
+    assert int(plan.export_table("omega_pow")[2]) == 9

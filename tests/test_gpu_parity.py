@@ -168,7 +168,7 @@ def test_modulus_sweep_every_word_size_both_policies(eng, oracle, n):
     for k in (20, 26, 31, 32, 33, 36, 41, 47, 52, 57, 60, 61, 62):
         for limit in (2 ** k, int(0.71 * 2 ** k)):
             q = ntt_prime_below(limit, n)
-            psi = numtheory.find_psi(n, q)
+            psi = numtheory.primitive_2n_root(n, q)
             plan = eng.Plan(n, q, psi)
             (seen_lazy if plan.is_lazy else seen_canon).add(q.bit_length())
             rng = np.random.default_rng(k)
@@ -461,7 +461,7 @@ def test_two_host_threads_with_their_own_plans(eng, oracle):
 @pytest.mark.parametrize("q", [8380417, 1152921504606830593])
 def test_fused_kernels_for_n512_n2048(eng, oracle, n, q):
     from tiny_ntt_amd import numtheory
-    psi = numtheory.find_psi(n, q)
+    psi = numtheory.primitive_2n_root(n, q)
     plan = eng.get_plan(n, q, psi)
     assert plan.has_fused and plan.is_lazy
     rng = np.random.default_rng(n + 1)

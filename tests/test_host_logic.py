@@ -106,7 +106,7 @@ def test_numtheory():
         omega = psi * psi % q
         r = numtheory.psi_from_omega(omega, n, q)
         assert r * r % q == omega and pow(r, n, q) == q - 1
-        found = numtheory.find_psi(n, q)
+        found = numtheory.primitive_2n_root(n, q)
         assert pow(found, n, q) == q - 1
     for p in (7681, 8380417, 1152921504606830593, 97):
         for a in (2, 3, 5, 10, 1234567):
@@ -115,7 +115,20 @@ def test_numtheory():
     with pytest.raises(ValueError, match="primitive"):
         numtheory.psi_from_omega(2, 256, 8380417)
     with pytest.raises(ValueError):
-        numtheory.find_psi(4096, 7681)
+        numtheory.primitive_2n_root(4096, 7681)
+
+
+def test_find_psi_returns_what_the_reference_script_returns():
+    """scripts/find_psi.py:9-43: the smallest psi in [2, max_search) with psi^n == -1, else None.  Expected values were
+    produced by importing that script (tests/golden/make_golden.py: find_psi_outputs)."""
+    import json
+    from conftest import GOLDEN as GOLDEN_DIR
+    cases = json.load(open(os.path.join(GOLDEN_DIR, "reference_find_psi.json")))
+    assert len(cases) >= 8 and any(c["psi"] is None for c in cases)
+    for c in cases:
+        assert numtheory.find_psi(c["n"], c["q"], c["max_search"]) == c["psi"], c
+    lines = []
+    assert numtheory.find_psi(4096, 8380417, log_fn=lines.append) == 687 and "687" in lines[0]
 
 
 def test_shard_rows_partition():

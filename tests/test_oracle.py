@@ -65,3 +65,19 @@ def test_oracle_reduces_unreduced_inputs(oracle):
 def test_literature_kat_n4(oracle, golden):
     g = golden("P4")           # test/refs/fast_ntt_negacyclic_convolution.py:161-214
     assert list(oracle.poly_mult(np.array([1, 2, 3, 4], dtype=np.uint64), np.array([5, 6, 7, 8], dtype=np.uint64), g.q, g.psi)) == [7625, 7645, 2, 60]
+
+
+def test_oracle_follows_the_reference_for_any_omega(oracle):
+    """The CPU restatement of cg_ntt / cg_intt against outputs of the reference for omegas that are not primitive roots
+    (tests/golden/make_golden.py: general_omega_cases)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "golden_general_omega.json")))
+    arrs = np.load(os.path.join(GOLDEN, "golden_general_omega.npz"))
+    assert len(meta) >= 8
+    for m in meta:
+        x, X = arrs[m["name"] + "_x"], arrs[m["name"] + "_X"]
+        assert np.array_equal(oracle.cg_ntt(x, m["omega"], m["q"]), X), m
+        if m.get("has_inverse"):
+            assert np.array_equal(oracle.cg_intt(X, m["omega"], m["q"]), arrs[m["name"] + "_inv"]), m

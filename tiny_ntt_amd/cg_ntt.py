@@ -47,7 +47,12 @@ def _as_words(values, modulus, dtype):
     return np.array([int(v) % modulus for v in values], dtype=dtype)
 
 
-def _plan_for_omega(n, omega_n, modulus):
+def _plan_for_omega(n, omega_n, modulus, variant):
+    """The reference evaluates cg_ntt for ANY omega_n (cg_ntt.py:29-65): the constant-geometry variants run on an
+    omega-only plan (no psi needed).  The register-tiled variants ("fused" / "auto") are keyed on psi, so they need
+    omega_n to be a primitive n-th root with a square root mod the modulus."""
+    if variant in engine.CG_VARIANTS:
+        return engine.get_omega_plan(n, modulus, omega_n, DEVICE)
     psi = numtheory.psi_from_omega(omega_n, n, modulus)
     return engine.get_plan(n, modulus, psi, DEVICE)
 
@@ -58,9 +63,9 @@ def cg_ntt(a_prime: List[int], omega_n: int, modulus: int = None, verbose: bool 
     modulus = Q if modulus is None else modulus
     if len(a_prime) != N:
         raise ValueError(f"Expected {N} coefficients, got {len(a_prime)}")
-    plan = _plan_for_omega(N, omega_n, modulus)
-    x = _as_words(a_prime, modulus, plan.dtype)
     variant = _variant or VARIANT
+    plan = _plan_for_omega(N, omega_n, modulus, variant)
+    x = _as_words(a_prime, modulus, plan.dtype)
     if not verbose:
         return [int(v) for v in plan.ntt_forward(x, variant=variant)]
     out, trace = plan.ntt_forward_trace(x, variant=variant)
@@ -81,8 +86,9 @@ def cg_intt(A: List[int], omega_n: int, modulus: int = None, _variant=None) -> L
     modulus = Q if modulus is None else modulus
     if len(A) != N:
         raise ValueError(f"Expected {N} coefficients, got {len(A)}")
-    plan = _plan_for_omega(N, omega_n, modulus)
-    return [int(v) for v in plan.ntt_inverse(_as_words(A, modulus, plan.dtype), variant=_variant or VARIANT)]
+    variant = _variant or VARIANT
+    plan = _plan_for_omega(N, omega_n, modulus, variant)
+    return [int(v) for v in plan.ntt_inverse(_as_words(A, modulus, plan.dtype), variant=variant)]
 
 
 def nwc_poly_mult(a: List[int], b: List[int], psi_2n: int, _variant=None) -> List[int]:

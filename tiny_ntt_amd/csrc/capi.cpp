@@ -131,6 +131,49 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   return TN_OK;
 }
 
+extern "C" tn_status tn_plan_create_omega(tn_plan** out, uint32_t n, uint64_t q, uint64_t omega, int device, uint32_t flags) {
+  if (!out) return fail(TN_EINVAL, "tn_plan_create_omega: out is NULL");
+  *out = nullptr;
+  u32 logn = 0;
+  while (((u32)1 << logn) < n) ++logn;
+  if (n < 4 || ((u32)1 << logn) != n) {
+    char buf[96]; snprintf(buf, sizeof buf, "Expected a power-of-two length >= 4, got %u", n);
+    return fail(TN_EBADLEN, buf);
+  }
+  if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
+  if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
+  const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
+  if (n > (elem_bytes == 8 ? 4096u : 8192u)) {
+    char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
+    return fail(TN_EBADLEN, buf);
+  }
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev <= 0) return fail(TN_ENODEVICE, "no HIP device visible; libtinyntt has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(TN_EINVAL, "device index out of range");
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+  tn_plan* p = new (std::nothrow) tn_plan();
+  if (!p) return fail(TN_ENOMEM, "plan allocation failed");
+  const HostTables t = h_build_omega_tables(n, q, omega);
+  p->n = n; p->logn = logn; p->q = q; p->psi = 0; p->omega = t.omega;
+  p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
+  p->k = t.k; p->lazy = false; p->cg_lazy = false; p->has_fused = false; p->omega_only = true;
+  if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount;
+  }
+  hipError_t e = upload_tw(t.omega_pow, t, false, &p->d_omega_pow);
+  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, false, &p->d_omega_inv_pow);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+  if (e != hipSuccess) { tn_plan_destroy(p); return fail_hip(e, "plan table upload"); }
+  *out = p;
+  return TN_OK;
+}
+
 extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   if (!p) return TN_OK;
   DeviceGuard guard(p->device);
@@ -191,6 +234,7 @@ extern "C" tn_status tn_poly_mult_dev(tn_plan* p, const void* a, const void* b, 
                                       void* stream) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_dev");
   if (st) return st;
+  if (p->omega_only) return fail(TN_EUNSUPPORTED, "tn_poly_mult_dev: an omega-only plan has no psi (tn_plan_create_omega offers cg_ntt / cg_intt only)");
   TN_ON_DEVICE(p);
   hipStream_t s = pick_stream(p, stream);
   if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
@@ -209,6 +253,7 @@ extern "C" tn_status tn_cyclic_poly_mult_dev(tn_plan* p, const void* a, const vo
                                              void* stream) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_cyclic_poly_mult_dev");
   if (st) return st;
+  if (p->omega_only) return fail(TN_EUNSUPPORTED, "tn_cyclic_poly_mult_dev: not available on an omega-only plan");
   TN_ON_DEVICE(p);
   if (variant == TN_VARIANT_AUTO) variant = p->has_fused ? TN_VARIANT_FUSED : TN_VARIANT_CG;
   if (variant == TN_VARIANT_FUSED) {
@@ -241,6 +286,7 @@ extern "C" tn_status tn_schoolbook_dev(tn_plan* p, const void* a, const void* b,
 
 extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out) {
   if (!p || !host_out) return fail(TN_EINVAL, "tn_plan_export_table: NULL argument");
+  if (p->omega_only && which != 2 && which != 3) return fail(TN_EUNSUPPORTED, "tn_plan_export_table: an omega-only plan has only the omega tables (2, 3)");
   const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv, p->d_psi_inv_pow};
   if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;
@@ -262,6 +308,7 @@ static tn_status ntt_dev(tn_plan* p, int mode, const void* in, void* out, size_t
                          void* trace, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st) return st;
+  if (p->omega_only && mode == CG_TWIST_FWD) return fail(TN_EUNSUPPORTED, std::string(fn) + ": an omega-only plan has no psi to twist with");
   TN_ON_DEVICE(p);
   if (variant == TN_VARIANT_AUTO) variant = (p->has_fused && !trace) ? TN_VARIANT_FUSED : TN_VARIANT_CG;
   if (variant == TN_VARIANT_FUSED) {

@@ -14,6 +14,7 @@ struct tn_plan {
   tn::u32 flags = 0;
   int elem_bytes = 8;
   bool has_fused = false, lazy = false, cg_lazy = false;
+  bool omega_only = false;   // created by tn_plan_create_omega: no psi, only the constant-geometry transforms
   int k = 0;            // bitlen(q)
   tn::Arith<tn::u64> ar64 = {};    // kernel-argument constants (h_make_arith); the one matching elem_bytes is used
   tn::Arith<tn::u32> ar32 = {};

@@ -218,6 +218,27 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   return t;
 }
 
+// Tables of an OMEGA-ONLY plan: cg_ntt(a, omega_n, modulus) / cg_intt for ANY omega_n (cg_ntt.py:29-75 only evaluates
+// the butterflies with pow(omega_n, k (i // k), modulus); the inverse uses modinv(omega_n) = omega_n^(q-2), :72, whatever
+// omega_n is).  No psi: only the constant-geometry transforms exist for such a plan.  Canonical policy (Shoup records).
+inline HostTables h_build_omega_tables(u32 n, u64 q, u64 omega) {
+  HostTables t;
+  u32 logn = 0;
+  while (((u32)1 << logn) < n) ++logn;
+  t.n = n; t.logn = logn; t.q = q; t.psi = 0; t.omega = omega % q;
+  t.elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
+  t.k = h_bitlen(q);
+  t.mu = (u64)((((unsigned __int128)1) << (2 * t.k)) / q);
+  t.lazy = false; t.cg_lazy = false; t.fold_c = 0;
+  const u64 omega_inv = h_powmod(t.omega, q - 2, q);             // modinv(omega_n): cg_ntt.py:9-10, :72
+  t.n_inv = h_powmod(n % q, q - 2, q);                           // :74
+  t.omega_pow.resize(n / 2); t.omega_inv_pow.resize(n / 2);
+  u64 w = 1 % q, wi = 1 % q;
+  for (u32 j = 0; j < n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
+  t.ninv_w1 = t.n_inv;
+  return t;
+}
+
 template <typename E> inline typename TwOf<E>::type h_make_tw(u64 w, u64 q);
 template <> inline Tw64 h_make_tw<u64>(u64 w, u64 q) { return h_make_tw64(w, q); }
 template <> inline Tw32 h_make_tw<u32>(u64 w, u64 q) { return h_make_tw32(w, q); }

@@ -34,7 +34,7 @@ PLAN_FORCE_CANONICAL = 1
 
 # Every symbol include/tinyntt.h declares (tests check the built library exports them all).
 EXPORTED_SYMBOLS = (
-    "tn_plan_create", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
+    "tn_plan_create", "tn_plan_create_omega", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
     "tn_plan_elem_bytes", "tn_plan_device", "tn_plan_has_fused", "tn_plan_is_lazy",
     "tn_poly_mult_dev", "tn_poly_mult_host", "tn_plan_set_host_chunk_rows", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
     "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib = ctypes.CDLL(p)
     vp, u32, u64, sz, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
     lib.tn_plan_create.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ci, u32]
+    lib.tn_plan_create_omega.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ci, u32]
     lib.tn_plan_destroy.argtypes = [vp]
     for name, res in (("tn_plan_n", u32), ("tn_plan_q", u64), ("tn_plan_psi", u64), ("tn_plan_omega", u64),
                       ("tn_plan_elem_bytes", u32), ("tn_plan_device", ci), ("tn_plan_has_fused", ci), ("tn_plan_is_lazy", ci)):
@@ -138,14 +139,20 @@ class Plan:
     (benchmark_ntt_60bit.cpp:43-64).
     """
 
-    def __init__(self, n: int, q: int, psi: int, device: int = 0, flags: int = 0):
+    def __init__(self, n: int, q: int, psi: int, device: int = 0, flags: int = 0, omega: int = None):
+        """omega given (psi ignored): an OMEGA-ONLY plan (tn_plan_create_omega) — cg_ntt / cg_intt for any omega_n."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         if not (0 <= int(n) < 2 ** 32):
             raise ValueError(f"Expected a power-of-two length >= 4, got {n}")
         if not (0 < int(q) < 2 ** 64):
             raise TinyNttError(TN_EBADPARAM, "q must be an odd prime below 2^62")
-        _check(self._lib, self._lib.tn_plan_create(ctypes.byref(self._h), int(n), int(q), int(psi) % int(q), int(device), int(flags)))
+        self.omega_only = omega is not None
+        if self.omega_only:
+            _check(self._lib, self._lib.tn_plan_create_omega(ctypes.byref(self._h), int(n), int(q), int(omega) % int(q), int(device), int(flags)))
+            psi = 0
+        else:
+            _check(self._lib, self._lib.tn_plan_create(ctypes.byref(self._h), int(n), int(q), int(psi) % int(q), int(device), int(flags)))
         self.n, self.q, self.psi = int(n), int(q), int(psi) % int(q)
         self.omega = int(self._lib.tn_plan_omega(self._h))
         self.elem_bytes = int(self._lib.tn_plan_elem_bytes(self._h))
@@ -376,6 +383,15 @@ def get_plan(n: int, q: int, psi: int, device: int = 0, flags: int = 0) -> Plan:
     p = _plan_cache.get(key)
     if p is None:
         p = _plan_cache[key] = Plan(*key)
+    return p
+
+
+def get_omega_plan(n: int, q: int, omega: int, device: int = 0) -> Plan:
+    """Cached omega-only plan: the transforms cg_ntt(a, omega_n, modulus) / cg_intt for any omega_n (cg_ntt.py:29-75)."""
+    key = ("omega", int(n), int(q), int(omega) % int(q), int(device))
+    p = _plan_cache.get(key)
+    if p is None:
+        p = _plan_cache[key] = Plan(int(n), int(q), 0, int(device), 0, omega=int(omega))
     return p
 
 

@@ -59,8 +59,25 @@ def psi_from_omega(omega: int, n: int, q: int) -> int:
     return min(r, q - r)
 
 
-def find_psi(n: int, q: int) -> int:
-    """Smallest primitive 2n-th root of unity mod q (scripts/find_psi.py:9-43 does a brute-force search)."""
+def find_psi(n: int, q: int, max_search: int = 10000, log_fn=None):
+    """The reference's parameter finder (scripts/find_psi.py:9-43): the SMALLEST psi in [2, max_search) with
+    psi^(2n) == 1 and psi^n == -1 (mod q), or None when that range holds none (e.g. the 60-bit set).  The reference
+    prints its progress; pass log_fn=print for the same two summary lines."""
+    for psi in range(2, max_search):
+        if pow(psi, 2 * n, q) == 1 and pow(psi, n, q) == q - 1:
+            if log_fn:
+                log_fn(f"\u2713 Found \u03c8 = {psi}")
+                log_fn(f"    \u03c9 = \u03c8\u00b2 = {psi * psi % q}")
+            return psi
+    if log_fn:
+        log_fn(f"\u2717 No \u03c8 found in range [2, {max_search})")
+    return None
+
+
+def primitive_2n_root(n: int, q: int) -> int:
+    """A primitive 2n-th root of unity mod the prime q for ANY admissible (n, q) (no search bound): the smallest
+    g^((q-1)/2n) over g < 2000 that has order exactly 2n.  Not a reference function (its finder is find_psi above,
+    which gives up beyond 10^4); used where tests need a psi for arbitrary moduli."""
     if (q - 1) % (2 * n):
         raise ValueError(f"2n={2 * n} does not divide q-1")
     e = (q - 1) // (2 * n)

@@ -27,12 +27,18 @@ STATE_IDLE, STATE_DONE = 0, 10          # debug_state field, bits [7:4] (ntt-tes
 
 
 class NttRoccSession:
-    def __init__(self, n: int, q: int, psi: int, device: int = 0, mode: str = "cyclic", variant: str = "auto"):
+    def __init__(self, n: int, q: int, psi: int, device: int = 0, mode: str = "cyclic", variant: str = "auto", width: int = None):
         if mode not in ("cyclic", "negacyclic"):
             raise ValueError("mode must be 'cyclic' or 'negacyclic'")
         self.plan = engine.get_plan(n, q, psi, device)
         self.n, self.q, self.mode, self.variant = n, q, mode, variant
-        self.addr_mask = n - 1                      # load_addr := rs1(addrWidth-1, 0)  (NttRocc.scala:187)
+        self.addr_mask = n - 1                      # load_addr := rs1(addrWidth-1, 0)  (NttRocc.scala:186)
+        # load_data := rs2(nttWidth-1, 0) (NttRocc.scala:187; nttWidth = 32 there, :95): the word is TRUNCATED to the
+        # coefficient width and stored as is, not reduced; the engine takes any stored word mod q when it is used
+        self.width = width if width is not None else (32 if self.plan.elem_bytes == 4 else 64)
+        if not 1 <= self.width <= 8 * self.plan.elem_bytes:
+            raise ValueError("width must fit the plan's coefficient word")
+        self.data_mask = (1 << self.width) - 1
         self._a = np.zeros(n, dtype=self.plan.dtype)
         self._b = np.zeros(n, dtype=self.plan.dtype)
         self._c = np.zeros(n, dtype=self.plan.dtype)
@@ -44,10 +50,10 @@ class NttRoccSession:
     def rocc(self, funct: int, rs1: int = 0, rs2: int = 0) -> int:
         """One custom instruction; returns rd (0 for instructions without a result)."""
         if funct == FUNCT_LOAD_A:
-            self._a[rs1 & self.addr_mask] = rs2 % self.q          # load_data := rs2(width-1, 0)
+            self._a[rs1 & self.addr_mask] = rs2 & self.data_mask  # load_data := rs2(width-1, 0)
             return 0
         if funct == FUNCT_LOAD_B:
-            self._b[rs1 & self.addr_mask] = rs2 % self.q
+            self._b[rs1 & self.addr_mask] = rs2 & self.data_mask
             return 0
         if funct == FUNCT_START:
             self._run()
