@@ -23,12 +23,14 @@
  *     hipStream_t passed as void* (NULL = the plan's own stream; TN_STREAM_LEGACY =
  *     the device's legacy default stream, hipStreamLegacy); they enqueue and return.  *_host entry points take host pointers, copy in, run, copy
  *     out and synchronise.
- *   - a, b are read-only; c must not alias a or b.
+ *   - a, b are read-only; c must not alias or overlap a or b (byte ranges are checked: TN_EINVAL).
  *   - Every function returns a tn_status; nothing throws or aborts across the
  *     ABI.  tn_last_error() gives the message for the calling thread.
- *   - A plan is immutable after creation; calls on one plan serialise on the
- *     stream they are given; distinct plans/devices may be used from distinct
- *     host threads.
+ *   - A plan's tables are immutable after creation.  *_dev calls on one plan serialise on the stream they are
+ *     given and may be issued from several host threads (also on different streams: the fused kernels' row
+ *     scheduler hands a counter slot to one launch at a time and falls back to a fixed stride when its ring is
+ *     busy).  *_host calls and tn_time_poly_mult_dev use the plan's staging buffers and events and take a
+ *     per-plan lock: concurrent callers are served one after the other.  Distinct plans/devices are independent.
  */
 #ifndef TINYNTT_H
 #define TINYNTT_H

@@ -207,3 +207,66 @@ def test_omega_only_plans_follow_the_reference_for_any_omega(eng):
         with pytest.raises(eng.TinyNttError):
             call()
     assert int(plan.export_table("omega_pow")[2]) == 9
+
+
+def test_two_host_threads_share_one_plan(eng, oracle):
+    """*_host entry points use the plan's staging buffers, streams and events: they take a per-plan lock, so two host
+    threads calling into ONE plan (with different batch sizes, which regrows the staging scratch) get correct results."""
+    import threading
+    n, q, psi = PARAMS["P1024"]
+    plan = eng.get_plan(n, q, psi)
+    rng = np.random.default_rng(77)
+    jobs = []
+    for rows in (3, 700, 40, 1500, 9, 300):
+        a = rng.integers(0, q, (rows, n), dtype=np.uint64).astype(plan.dtype); b = rng.integers(0, q, (rows, n), dtype=np.uint64).astype(plan.dtype)
+        jobs.append((a, b))
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                for j, (a, b) in enumerate(jobs):
+                    if (j + tid) % 2 == 0:
+                        results[(tid, rep, j)] = plan.poly_mult(a, b)
+                    else:
+                        results[(tid, rep, j)] = plan.ntt_inverse(plan.ntt_forward(a))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    ref = [oracle.poly_mult(a.astype(np.uint64), b.astype(np.uint64), q, psi) for a, b in jobs]
+    for (tid, rep, j), got in results.items():
+        if (j + tid) % 2 == 0:
+            assert np.array_equal(got.astype(np.uint64), ref[j]), (tid, rep, j)
+        else:
+            assert np.array_equal(got, jobs[j][0]), (tid, rep, j)
+
+
+def test_overlapping_output_is_rejected_and_many_streams_stay_correct(eng):
+    import torch
+    n, q, psi = PARAMS["P4096_60"]
+    plan = eng.get_plan(n, q, psi)
+    buf = plan.fill_lcg(12, 1, 1)
+    a, b = buf[0:4], buf[4:8]
+    with pytest.raises(eng.TinyNttError, match="overlap"):
+        plan.poly_mult(a, b, out=buf[2:6])                 # c overlaps the tail of a and the head of b
+    with pytest.raises(eng.TinyNttError, match="overlap"):
+        plan.ntt_forward(buf[0:4], out=buf[3:7])
+    # launches on several streams at once share the scheduler ring: every result must still be right
+    rows = 20000                                           # large enough for dynamic row scheduling
+    A = plan.fill_lcg(rows, 1, 2); B = plan.fill_lcg(rows, 2, 2)
+    ref = plan.poly_mult(A, B)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.empty_like(A) for _ in streams]
+    for rep in range(3):
+        for s, o in zip(streams, outs):
+            plan.poly_mult(A, B, out=o, stream=s)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)

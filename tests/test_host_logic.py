@@ -140,3 +140,18 @@ def test_shard_rows_partition():
             for (s0, c0), (s1, _) in zip(spans, spans[1:]):
                 assert s0 + c0 == s1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_host_rows_take_integers_mod_q_and_refuse_floats():
+    """Plan._host_rows (no device needed): any Python / numpy integer is taken mod q like the reference's %, floats raise."""
+    class P:                                            # stand-in with the attributes _host_rows reads
+        q, dtype, elem_bytes, n = 8380417, np.uint32, 4, 4
+    f = engine.Plan._host_rows
+    assert f(P(), [1, 2, 3, 4], "a").tolist() == [[1, 2, 3, 4]]
+    assert f(P(), [-1, 2 ** 70, 3, 4], "a").tolist() == [[8380416, 2 ** 70 % 8380417, 3, 4]]
+    assert f(P(), np.array([-1, 2, 3, 4]), "a").tolist() == [[8380416, 2, 3, 4]]
+    assert f(P(), np.array([2 ** 40, 2, 3, 4], dtype=np.uint64), "a").tolist() == [[2 ** 40 % 8380417, 2, 3, 4]]
+    with pytest.raises(TypeError):
+        f(P(), [1.5, 2, 3, 4], "a")
+    with pytest.raises(ValueError):
+        f(P(), [1, 2, 3], "a")

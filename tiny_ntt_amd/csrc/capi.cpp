@@ -179,6 +179,7 @@ extern "C" tn_status tn_plan_destroy(tn_plan* p) {
   DeviceGuard guard(p->device);
   void* tabs[] = {p->d_psi_brv, p->d_psi_inv_brv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_pow, p->d_psi_inv_ninv, p->d_psi_inv_pow, p->d_cyc_brv, p->d_cyc_inv_brv, p->d_scratch, p->d_sched};
   for (void* t : tabs) if (t) (void)hipFree(t);
+  for (unsigned i = 0; i < tn_plan::SCHED_SLOTS; ++i) if (p->sched_ev[i]) (void)hipEventDestroy(p->sched_ev[i]);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   for (int i = 0; i < tn_plan::HOST_SLOTS; ++i) {
@@ -226,7 +227,12 @@ static tn_status check_ptrs(const tn_plan* p, const void* a, const void* b, cons
   if (!p) return fail(TN_EINVAL, std::string(fn) + ": plan is NULL");
   if (batch > 0x7fffffffull) return fail(TN_EINVAL, std::string(fn) + ": batch too large for one call (max 2^31 - 1 rows)");
   if (batch && (!a || !b || !c)) return fail(TN_EINVAL, std::string(fn) + ": NULL buffer");
-  if (batch && (c == a || c == b)) return fail(TN_EINVAL, std::string(fn) + ": output must not alias an input");
+  if (batch) {                        // byte ranges: the kernels prefetch the next row's input while a row's result is being stored
+    const size_t bytes = batch * (size_t)p->n * (size_t)p->elem_bytes;
+    const char *ca = (const char*)a, *cb = (const char*)b, *cc = (const char*)c;
+    if ((cc < ca + bytes && ca < cc + bytes) || (cc < cb + bytes && cb < cc + bytes))
+      return fail(TN_EINVAL, std::string(fn) + ": output must not alias or overlap an input");
+  }
   return TN_OK;
 }
 
@@ -430,6 +436,7 @@ static tn_status host_pipeline_run(tn_plan* p, int n_in, const void* const* in, 
 
 extern "C" tn_status tn_plan_set_host_chunk_rows(tn_plan* p, size_t rows) {
   if (!p) return fail(TN_EINVAL, "tn_plan_set_host_chunk_rows: plan is NULL");
+  std::lock_guard<std::mutex> host_lock(p->host_mu);
   p->host_chunk_rows = rows;
   return TN_OK;
 }
@@ -437,6 +444,7 @@ extern "C" tn_status tn_plan_set_host_chunk_rows(tn_plan* p, size_t rows) {
 extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b, void* c, size_t batch, tn_variant variant) {
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_poly_mult_host");
   if (st || batch == 0) return st;
+  std::lock_guard<std::mutex> host_lock(p->host_mu);
   TN_ON_DEVICE(p);
   const void* in[2] = {a, b};
   return host_pipeline(p, 2, in, c, batch, [&](const void* da, const void* db, void* dc, size_t rows) {
@@ -447,6 +455,7 @@ extern "C" tn_status tn_poly_mult_host(tn_plan* p, const void* a, const void* b,
 static tn_status ntt_host(tn_plan* p, int mode, const void* in, void* out, void* trace, size_t batch, tn_variant v, const char* fn) {
   tn_status st = check_ptrs(p, in, in, out, batch, fn);
   if (st || batch == 0) return st;
+  std::lock_guard<std::mutex> host_lock(p->host_mu);
   TN_ON_DEVICE(p);
   if (!trace) {
     const void* ins[1] = {in};
@@ -505,6 +514,7 @@ extern "C" tn_status tn_time_poly_mult_dev(tn_plan* p, const void* a, const void
   if (!ms_per_launch || iters < 1) return fail(TN_EINVAL, "tn_time_poly_mult_dev: bad iters/ms pointer");
   tn_status st = check_ptrs(p, a, b, c, batch, "tn_time_poly_mult_dev");
   if (st) return st;
+  std::lock_guard<std::mutex> host_lock(p->host_mu);
   TN_ON_DEVICE(p);
   TN_HIP(hipEventRecord(p->ev0, p->stream));
   for (int i = 0; i < iters; ++i)

@@ -483,10 +483,13 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   const size_t chunks = (batch + chunk - 1) / chunk;
   const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
-  u32* sched = nullptr;               // dynamic hand-out only pays when every workgroup takes several chunks
-  if (TN_DYNAMIC_ROWS && p->d_sched && chunks >= 4 * resident) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
+  SchedSlot slot;                     // dynamic hand-out only pays when every workgroup takes several chunks
+  if (TN_DYNAMIC_ROWS && chunks >= 4 * resident) slot = sched_acquire(p);
+  u32* sched = slot.ptr;
   void* args[] = {&ar, &tab, &in_, &out_, &b32, &sched, &chunk};
-  return hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
+  const hipError_t le = hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
+  sched_release(p, slot, s);
+  return le;
 }
 
 template <typename E, bool LAZY>
@@ -538,11 +541,14 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   Arith<E> ar = pv.ar;
   if (cyclic) ar.fninv_w1 = ar.fninv;
   // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
-  u32* sched = nullptr;               // (only pays when every workgroup takes several chunks; a short launch keeps the fixed stride)
-  if (TN_DYNAMIC_ROWS && p->d_sched && chunks >= 4 * resident) sched = p->d_sched + 2 * (p->sched_seq.fetch_add(1u) % tn_plan::SCHED_SLOTS);
+  SchedSlot slot;                     // (only pays when every workgroup takes several chunks; a short launch keeps the fixed stride)
+  if (TN_DYNAMIC_ROWS && chunks >= 4 * resident) slot = sched_acquire(p);
+  u32* sched = slot.ptr;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
                      cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched, chunk);
-  return hipGetLastError();
+  const hipError_t le = hipGetLastError();
+  sched_release(p, slot, s);
+  return le;
 }
 
 template <typename E, bool LAZY>

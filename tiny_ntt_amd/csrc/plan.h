@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <atomic>
+#include <mutex>
 #include "fused_core.h"
 
 struct tn_plan {
@@ -38,11 +39,20 @@ struct tn_plan {
   void* d_cyc_brv = nullptr;       // [n]   merged twiddles of the cyclic transform (HostTables::cyc_brv): fused cg_ntt
   void* d_cyc_inv_brv = nullptr;   // [n]   their inverses: fused cg_intt
   void* d_psi_inv_ninv = nullptr;  // [n]   psi^-i * n^-1  (untwist :92 fused with the n^-1 of :74-75)
+  // Host-side mutable state (staging scratch, the host pipeline's streams / events, ev0 / ev1 of the timing helper): the
+  // *_host entry points and tn_time_poly_mult_dev take this lock, so two host threads may share one plan; *_dev entry
+  // points touch none of it.
+  mutable std::mutex host_mu;
   // dynamic row scheduling of the persistent fused kernel: SCHED_SLOTS pairs {next row, finished workgroups}, zeroed at
   // plan creation and re-armed by the kernel itself; consecutive launches take consecutive slots
-  static constexpr unsigned SCHED_SLOTS = 4096;   // a slot is reused only 4096 launches later: long before that its launch has retired
+  // a slot is handed out again only after the launch that used it last has retired (an event per slot, queried on reuse:
+  // sched_acquire); while it is still busy the new launch falls back to the fixed stride, which is always correct
+  static constexpr unsigned SCHED_SLOTS = 1024;     // launches that can be in flight with dynamic scheduling before the fallback applies
   tn::u32* d_sched = nullptr;
-  mutable std::atomic<unsigned> sched_seq{0};
+  mutable std::mutex sched_mu;
+  mutable unsigned sched_seq = 0;
+  mutable hipEvent_t sched_ev[SCHED_SLOTS] = {};
+  mutable bool sched_used[SCHED_SLOTS] = {};
   void* d_scratch = nullptr;       // host-entry staging (grown on demand)
   size_t scratch_bytes = 0;
 };
@@ -82,6 +92,25 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
   v.psi_inv_pow = (const Tw*)p->d_psi_inv_pow;
   v.cyc_brv = (const Tw*)p->d_cyc_brv; v.cyc_inv_brv = (const Tw*)p->d_cyc_inv_brv;
   return v;
+}
+
+// Dynamic-row-scheduler slot for one launch on stream s, or nullptr (fixed stride) when the ring's next slot is still in
+// use by an earlier launch (possible across streams); sched_release records the slot's event after the launch.
+struct SchedSlot { u32* ptr = nullptr; int index = -1; };
+inline SchedSlot sched_acquire(const tn_plan* p) {
+  SchedSlot r;
+  if (!p->d_sched) return r;
+  std::lock_guard<std::mutex> g(p->sched_mu);
+  const unsigned i = p->sched_seq % tn_plan::SCHED_SLOTS;
+  if (p->sched_used[i] && hipEventQuery(p->sched_ev[i]) != hipSuccess) return r;     // still running (or errored): do not share it
+  if (!p->sched_ev[i] && hipEventCreateWithFlags(&p->sched_ev[i], hipEventDisableTiming) != hipSuccess) return r;
+  ++p->sched_seq;
+  p->sched_used[i] = true;
+  r.ptr = p->d_sched + 2 * i; r.index = (int)i;
+  return r;
+}
+inline void sched_release(const tn_plan* p, const SchedSlot& s, hipStream_t stream) {
+  if (s.index >= 0) (void)hipEventRecord(p->sched_ev[s.index], stream);
 }
 
 // kernels.hip

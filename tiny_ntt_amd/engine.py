@@ -180,7 +180,16 @@ class Plan:
         return torch.int32 if self.elem_bytes == 4 else torch.int64   # bit patterns are unsigned
 
     def _host_rows(self, x, name):
-        arr = np.ascontiguousarray(x, dtype=self.dtype)
+        arr = np.asarray(x)
+        if arr.dtype == object:                     # Python ints of any size / sign: taken mod q like the reference's % (cg_ntt.py:82-83)
+            arr = np.array([int(v) % self.q for v in arr.ravel()], dtype=self.dtype).reshape(arr.shape)
+        elif arr.dtype.kind == "i":                 # signed words: Python's % is non-negative
+            arr = np.mod(arr.astype(np.int64), self.q).astype(self.dtype) if arr.size and arr.min() < 0 else arr
+        elif arr.dtype.kind not in "u":
+            raise TypeError(f"{name}: coefficients must be integers, got dtype {arr.dtype}")
+        if arr.dtype.itemsize > self.elem_bytes and arr.size and int(arr.max()) >= 2 ** (8 * self.elem_bytes):
+            arr = np.mod(arr, self.q)               # wider words than the plan's lanes: reduce instead of truncating
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
         if arr.ndim == 1:
             arr = arr[None, :]
         if arr.ndim != 2 or arr.shape[1] != self.n:
