@@ -79,10 +79,11 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
   // that the address is ADDITIVE in the register index on both sides of the transpose (ex_base + ex_off below): one
   // address register per side and immediate offsets, instead of one register per coefficient (which, as loop invariants
   // of the persistent row loop, cost ~30 VGPRs and pushed the n = 4096 kernel into scratch).
-  // 8-byte lanes, last exchange: one pad element per R coefficients (64-bit accesses on both sides are then
-  // bank-conflict free; no padding makes 128-bit accesses of the owning side AND the 64-bit ones of the other
-  // side conflict free at once: tests/test_lds_banks.py).
-  static constexpr int ex_pad(int e) { return pos(e + 1) > 0 ? (1 << pos(e + 1)) : (sizeof(E) == 8 ? 1 : (int)(16 / sizeof(E))); }
+  // Last exchange (into the phase whose threads own R consecutive coefficients): ONE pad element per R coefficients.
+  // Element-wide accesses on both sides are then bank-conflict free for both lane widths (no padding makes the wider
+  // 128-bit accesses of the owning side AND the element-wide ones of the other side conflict free at once:
+  // tests/test_lds_banks.py, tools/lds_layout_search.py).
+  static constexpr int ex_pad(int e) { return pos(e + 1) > 0 ? (1 << pos(e + 1)) : 1; }
   static constexpr int ex_sh(int e) { return pos(e + 1) > 0 ? pos(e + 1) + LPT : LPT; }
   static constexpr int lay_span(int e, int cnt) { return cnt + ex_pad(e) * (cnt >> ex_sh(e)); }
   // Waves: thread-id bits >= 6.  WB of them; in every phase after the first they are the top

@@ -65,15 +65,17 @@
 #endif
 namespace tn {
 
-// Rows handed out per atomicAdd of the dynamic row scheduler: TN_SCHED_CHUNK_BYTES worth of rows (2 at n = 4096 with
-// 64-bit lanes, 64 at n = 256 with 32-bit lanes) so the one counter address never becomes the bottleneck (one row per
-// atomic at n = 256 ran 13x slower than a fixed stride), but never so many that a small batch yields fewer than four
-// chunks per resident workgroup.
-static inline u32 sched_chunk_rows(size_t row_bytes, size_t batch, size_t resident) {
-  size_t c = (size_t)TN_SCHED_CHUNK_BYTES / row_bytes;
-  const size_t cap = batch / (4 * resident);
-  if (c > cap) c = cap;
-  return (u32)(c < 1 ? 1 : c);
+// Row hand-out of the persistent fused kernels.  Dynamic (one atomicAdd on a device counter per chunk of rows) when the
+// launch is long enough for every resident workgroup to take at least four chunks of TN_SCHED_CHUNK_BYTES worth of rows
+// (2 rows at n = 4096 / 64-bit, 16 at n = 1024 / 32-bit): a chunk that large keeps the one counter address from becoming
+// the bottleneck (one row per atomic at n = 256 ran 13x slower than a fixed stride; at n = 1024 / 24-bit, batch 16,384, 10x).
+// Otherwise a fixed stride of single rows.
+struct RowPlan { u32 chunk; bool dynamic; };
+static inline RowPlan plan_rows(size_t row_bytes, size_t batch, size_t resident) {
+  size_t want = (size_t)TN_SCHED_CHUNK_BYTES / row_bytes;
+  if (want < 1) want = 1;
+  if (TN_DYNAMIC_ROWS && batch >= 4 * resident * want) return {(u32)want, true};
+  return {1u, false};
 }
 
 // ============================================================================
@@ -479,12 +481,13 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
-  u32 chunk = sched_chunk_rows(Cfg::N * sizeof(E), batch, resident);
+  const RowPlan rp = plan_rows(Cfg::N * sizeof(E), batch, resident);
+  u32 chunk = rp.chunk;
   const size_t chunks = (batch + chunk - 1) / chunk;
   const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
-  SchedSlot slot;                     // dynamic hand-out only pays when every workgroup takes several chunks
-  if (TN_DYNAMIC_ROWS && chunks >= 4 * resident) slot = sched_acquire(p);
+  SchedSlot slot;
+  if (rp.dynamic) slot = sched_acquire(p);
   u32* sched = slot.ptr;
   void* args[] = {&ar, &tab, &in_, &out_, &b32, &sched, &chunk};
   const hipError_t le = hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
@@ -532,7 +535,8 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Cfg::THREADS, lds_bytes);
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
-  const u32 chunk = sched_chunk_rows(Cfg::N * sizeof(E), batch, resident);
+  const RowPlan rp = plan_rows(Cfg::N * sizeof(E), batch, resident);
+  const u32 chunk = rp.chunk;
   const size_t chunks = (batch + chunk - 1) / chunk;
   const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const PlanView<E> pv = make_view<E>(p);
@@ -541,8 +545,8 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   Arith<E> ar = pv.ar;
   if (cyclic) ar.fninv_w1 = ar.fninv;
   // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
-  SchedSlot slot;                     // (only pays when every workgroup takes several chunks; a short launch keeps the fixed stride)
-  if (TN_DYNAMIC_ROWS && chunks >= 4 * resident) slot = sched_acquire(p);
+  SchedSlot slot;
+  if (rp.dynamic) slot = sched_acquire(p);
   u32* sched = slot.ptr;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
                      cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched, chunk);

@@ -3,7 +3,7 @@
 import csv, glob, os, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(list)
-for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
+for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")
