@@ -86,7 +86,7 @@ typedef struct tn_plan tn_plan;
  * Replaces: module constants N, Q (cg_ntt.py:5-6) + the psi_2n argument of
  * nwc_poly_mult (:78); BENCH_N/BENCH_Q/BENCH_PSI (software_benchmark/CMakeLists.txt:5-7)
  * and the constexpr tables PsiPowers/OmegaPowers/... (benchmark_ntt_60bit.cpp:43-64).
- * Validates n = 2^m (4 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q).
+ * Validates n = 2^m (4 <= n <= 8192; fused kernels for 256 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q).
  */
 tn_status tn_plan_create(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags);
 /*

@@ -142,6 +142,7 @@ int fused_ntt_dispatch(const HostTables& t, int mode, const u64* in, u64* out) {
     case 10: return fused_ntt_emu<E, 10, fused_lpt(10), LAZY>(t, mode, in, out);
     case 11: return fused_ntt_emu<E, 11, fused_lpt(11), LAZY>(t, mode, in, out);
     case 12: return fused_ntt_emu<E, 12, fused_lpt(12), LAZY>(t, mode, in, out);
+    case 13: return fused_ntt_emu<E, 13, fused_lpt(13), LAZY>(t, mode, in, out);
     default: return 7;
   }
 }
@@ -154,6 +155,7 @@ int fused_dispatch(const HostTables& t, const u64* a, const u64* b, u64* c, size
     case 10: return fused_polymul_emu<E, 10, fused_lpt(10), LAZY>(t, a, b, c, batch, cyclic);
     case 11: return fused_polymul_emu<E, 11, fused_lpt(11), LAZY>(t, a, b, c, batch, cyclic);
     case 12: return fused_polymul_emu<E, 12, fused_lpt(12), LAZY>(t, a, b, c, batch, cyclic);
+    case 13: return fused_polymul_emu<E, 13, fused_lpt(13), LAZY>(t, a, b, c, batch, cyclic);
     default: return 7;
   }
 }
@@ -269,12 +271,14 @@ long emu_cfg_probe(int logn, int elem_bytes, int what, unsigned a0, unsigned a1,
     if (logn == 10) return cfg_probe<u64, 10, fused_lpt(10)>(what, a0, a1, a2);
     if (logn == 11) return cfg_probe<u64, 11, fused_lpt(11)>(what, a0, a1, a2);
     if (logn == 12) return cfg_probe<u64, 12, fused_lpt(12)>(what, a0, a1, a2);
+    if (logn == 13) return cfg_probe<u64, 13, fused_lpt(13)>(what, a0, a1, a2);
   } else {
     if (logn == 8) return cfg_probe<u32, 8, fused_lpt(8)>(what, a0, a1, a2);
     if (logn == 9) return cfg_probe<u32, 9, fused_lpt(9)>(what, a0, a1, a2);
     if (logn == 10) return cfg_probe<u32, 10, fused_lpt(10)>(what, a0, a1, a2);
     if (logn == 11) return cfg_probe<u32, 11, fused_lpt(11)>(what, a0, a1, a2);
     if (logn == 12) return cfg_probe<u32, 12, fused_lpt(12)>(what, a0, a1, a2);
+    if (logn == 13) return cfg_probe<u32, 13, fused_lpt(13)>(what, a0, a1, a2);
   }
   return -1;
 }
@@ -320,6 +324,7 @@ long emu_split_sched_stat(int logn, int what) {
     case 10: return stat(FusedCfg<u64, 10, fused_lpt(10)>());
     case 11: return stat(FusedCfg<u64, 11, fused_lpt(11)>());
     case 12: return stat(FusedCfg<u64, 12, fused_lpt(12)>());
+    case 13: return stat(FusedCfg<u64, 13, fused_lpt(13)>());
   }
   return -1;
 }

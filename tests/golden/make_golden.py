@@ -224,9 +224,38 @@ def general_omega_cases():
     print("general omega cases:", len(meta))
 
 
+def n8192_cases():
+    """n = 8192 at the reference's 60-bit modulus (the largest negacyclic size it admits: 2n = 2^14 divides q - 1 exactly):
+    N overridden on the reference modules (cg_ntt.py:5), psi = a primitive 16384-th root of unity.  Product, forward
+    transform and first-16 stage traces of one seeded pair, plus a sparse wrap-around case."""
+    n, q = 8192, 1152921504606830593
+    psi = 458558429756866                                   # numtheory.primitive_2n_root(8192, q); psi^8192 == -1
+    assert pow(psi, n, q) == q - 1
+    omega = psi * psi % q
+    set_params(n, q)
+    rng = random.Random(8192)
+    a = [rng.randrange(q) for _ in range(n)]; b = [rng.randrange(q) for _ in range(n)]
+    arrays = {"a": u64(a), "b": u64(b), "c": u64(ref.nwc_poly_mult(a, b, psi)), "c8": u64(ref8.nwc_poly_mult_8butterfly(a, b, psi))}
+    assert np.array_equal(arrays["c"], arrays["c8"])
+    X, tr, _bitrev = trace_of(ref.cg_ntt, a, omega, q)
+    arrays["a_ntt"], arrays["a_trace16"] = u64(X), u64(tr)
+    assert ref.cg_intt(X, omega, q) == a
+    xm = [0] * n; xm[n - 1] = 1; x1 = [0] * n; x1[1] = 1     # x^(n-1) * x = -1
+    arrays["wrap_c"] = u64(ref.nwc_poly_mult(xm, x1, psi))
+    assert arrays["wrap_c"][0] == q - 1
+    np.savez_compressed(os.path.join(HERE, "golden_P8192_60.npz"), **arrays)
+    with open(os.path.join(HERE, "golden_P8192_60.json"), "w") as f:
+        json.dump({"n": n, "q": q, "psi": psi, "omega": omega}, f, indent=1)
+    print("n=8192 cases:", sorted(arrays))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "n8192":
+        n8192_cases()
+        sys.exit(0)
     for tag in PARAMS:
         gen(tag)
+    n8192_cases()
     hex_digests()
     find_psi_outputs()
     general_omega_cases()

@@ -222,3 +222,27 @@ def test_fused_standalone_transforms_other_sizes(emu, oracle, n):
         X = oracle.cg_ntt(x, omega, q)
         assert np.array_equal(emu.fused_ntt(n, q, psi, 1, x), X)
         assert np.array_equal(emu.fused_ntt(n, q, psi, 2, X), x % np.uint64(q))
+
+
+def test_n8192_60bit_emulation_and_oracle_match_reference_golden(emu, oracle):
+    """n = 8192 at the reference's 60-bit modulus (vectors: tests/golden/make_golden.py n8192_cases, N overridden on the
+    reference modules): the CPU oracle and the CPU stepping of the fused kernels (five register phases, the fourth with
+    vector-loaded twiddles) both reproduce the reference's product, forward transform and stage traces."""
+    import json
+    import os
+    from conftest import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "golden_P8192_60.json")))
+    g = np.load(os.path.join(GOLDEN, "golden_P8192_60.npz"))
+    n, q, psi, omega = meta["n"], meta["q"], meta["psi"], meta["omega"]
+    X, tr = oracle.cg_ntt(g["a"], omega, q, trace=True)
+    assert np.array_equal(X, g["a_ntt"]) and np.array_equal(tr[:, :16], g["a_trace16"])
+    assert np.array_equal(oracle.poly_mult(g["a"], g["b"], q, psi), g["c"])
+    assert emu.lib.emu_is_lazy(n, q, psi) == 1
+    for canonical in (False, True):
+        got = emu.fused(n, q, psi, np.stack([g["a"], g["b"]]), np.stack([g["b"], g["a"]]), canonical)
+        assert np.array_equal(got[0], g["c"]) and np.array_equal(got[1], g["c"])
+        assert np.array_equal(emu.fused_ntt(n, q, psi, 1, g["a"], canonical), g["a_ntt"])
+        assert np.array_equal(emu.fused_ntt(n, q, psi, 2, g["a_ntt"], canonical), g["a"])
+    xm = np.zeros(n, dtype=np.uint64); xm[n - 1] = 1
+    x1 = np.zeros(n, dtype=np.uint64); x1[1] = 1
+    assert np.array_equal(emu.fused(n, q, psi, xm[None], x1[None])[0], g["wrap_c"])

@@ -5,10 +5,12 @@ at BASELINE.json's full sizes — satisfy size-independent properties (reference
 linearity, commutativity, identity, wrap-around)."""
 import random
 
+import os
+
 import numpy as np
 import pytest
 
-from conftest import PARAMS, REF_CHECKSUMS, ntt_prime_below
+from conftest import GOLDEN, PARAMS, REF_CHECKSUMS, ntt_prime_below
 
 pytestmark = pytest.mark.gpu
 
@@ -470,3 +472,41 @@ def test_fused_kernels_for_n512_n2048(eng, oracle, n, q):
     ref = oracle.poly_mult(a, b, q, psi)
     for v in variants_of(plan):
         assert np.array_equal(plan.poly_mult(a.astype(plan.dtype), b.astype(plan.dtype), variant=v).astype(np.uint64), ref), (n, q, v)
+
+
+def test_n8192_60bit_matches_reference_golden_and_oracle(eng, oracle):
+    """n = 8192 at the reference's 60-bit modulus: the largest negacyclic size that modulus admits (2n = 2^14 | q - 1).  Golden
+    vectors from the reference with N overridden (tests/golden/make_golden.py n8192_cases); every variant, both policies."""
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "golden_P8192_60.json")))
+    g = np.load(os.path.join(GOLDEN, "golden_P8192_60.npz"))
+    n, q, psi, omega = meta["n"], meta["q"], meta["psi"], meta["omega"]
+    plan = eng.get_plan(n, q, psi)
+    cplan = eng.get_plan(n, q, psi, 0, eng.PLAN_FORCE_CANONICAL)
+    assert plan.has_fused and plan.is_lazy and plan.omega == omega and not cplan.is_lazy
+    a, b = g["a"][None].copy(), g["b"][None].copy()
+    for p in (plan, cplan):
+        for v in ("fused", "cg", "cg8", "cg4_swizzled", "cg2_padded"):
+            assert np.array_equal(p.poly_mult(a, b, variant=v)[0], g["c"]), v
+        for v in ("fused", "cg", "cg8"):
+            assert np.array_equal(p.ntt_forward(g["a"], variant=v), g["a_ntt"]), v
+            assert np.array_equal(p.ntt_inverse(g["a_ntt"], variant=v), g["a"]), v
+        out, trace = p.ntt_forward_trace(g["a"], variant="cg")
+        assert np.array_equal(out, g["a_ntt"]) and np.array_equal(trace[:, :16], g["a_trace16"])
+    xm = np.zeros(n, dtype=np.uint64); xm[n - 1] = 1
+    x1 = np.zeros(n, dtype=np.uint64); x1[1] = 1
+    assert np.array_equal(plan.poly_mult(xm, x1), g["wrap_c"])
+    # a random batch through the persistent kernel (several rows per workgroup), incl. unreduced words, vs the CPU oracle
+    rng = np.random.default_rng(8192)
+    B = 300
+    A = rng.integers(0, q, (B, n), dtype=np.uint64); Bm = rng.integers(0, q, (B, n), dtype=np.uint64)
+    A[0], Bm[0] = q - 1, q - 1
+    A[1] = rng.integers(0, 2 ** 64 - 1, n, dtype=np.uint64, endpoint=True); Bm[1] = 2 ** 64 - 1
+    ref = oracle.poly_mult(A[:8], Bm[:8], q, psi)
+    got = plan.poly_mult(A, Bm)
+    assert np.array_equal(got[:8], ref)
+    assert np.array_equal(got, plan.poly_mult(A, Bm, variant="cg"))
+    assert np.array_equal(cplan.poly_mult(A[:40], Bm[:40]), got[:40])
+    X = plan.ntt_forward(A[:40])
+    assert np.array_equal(X, plan.ntt_forward(A[:40], variant="cg")) and np.array_equal(plan.ntt_inverse(X), A[:40] % np.uint64(q))
+    assert np.array_equal(plan.cyclic_poly_mult(A[:40], Bm[:40]), plan.cyclic_poly_mult(A[:40], Bm[:40], variant="cg"))

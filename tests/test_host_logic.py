@@ -46,7 +46,7 @@ def test_plan_validation_errors_precede_device_use():
     with pytest.raises(ValueError):
         engine.Plan(2, q, psi)
     with pytest.raises(ValueError, match="exceeds"):
-        engine.Plan(8192, q, psi)
+        engine.Plan(16384, q, psi)
     with pytest.raises(engine.TinyNttError, match="psi") as e:
         engine.Plan(n, q, psi + 1)
     assert e.value.status == engine.TN_EBADPARAM

@@ -82,7 +82,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
   if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
   const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
-  if (n > (elem_bytes == 8 ? 4096u : 8192u)) {
+  if (n > 8192u) {
     char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
     return fail(TN_EBADLEN, buf);
   }
@@ -143,7 +143,7 @@ extern "C" tn_status tn_plan_create_omega(tn_plan** out, uint32_t n, uint64_t q,
   if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
   if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
   const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
-  if (n > (elem_bytes == 8 ? 4096u : 8192u)) {
+  if (n > 8192u) {
     char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
     return fail(TN_EBADLEN, buf);
   }

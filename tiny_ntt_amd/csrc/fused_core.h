@@ -48,7 +48,7 @@ template <int B, int E_, typename F> TN_HD void static_for(F&& f) { StaticFor<B,
 #define TN_FUSED_LPT12 3         // n = 4096
 #endif
 constexpr int fused_lpt(int logn) {
-  return logn == 8 ? 2 : logn == 9 ? 3 : logn == 10 ? TN_FUSED_LPT10 : logn == 11 ? 3 : logn == 12 ? TN_FUSED_LPT12 : 0;
+  return logn == 8 ? 2 : logn == 9 ? 3 : logn == 10 ? TN_FUSED_LPT10 : logn == 11 ? 3 : logn == 12 ? TN_FUSED_LPT12 : logn == 13 ? 3 : 0;
 }
 
 // Per-plan arithmetic constants, passed by value to kernels (lives in SGPRs).
@@ -131,9 +131,13 @@ template <typename E, int LOGN_, int LPT_> struct FusedCfg {
   //   TW_LDS      lane-dependent, table small: staged once per workgroup in LDS
   //   TW_REGS     last phase: one private set per thread, fetched from the L2-resident table into
   //               registers (pre[]) just before the transpose that precedes the phase
-  enum { TW_UNIFORM = 0, TW_WAVE = 1, TW_LDS = 2, TW_REGS = 3 };
+  //   TW_VEC      lane-dependent and too many for LDS (table indices >= 2^LDS_TW_MAX_STAGE: only n = 8192, whose
+  //               second-to-last phase uses 3584 records): vector loads from the L2-resident table at use
+  enum { TW_UNIFORM = 0, TW_WAVE = 1, TW_LDS = 2, TW_REGS = 3, TW_VEC = 4 };
+  static constexpr int LDS_TW_MAX_STAGE = 9;         // LDS holds table entries below 2^9 (8 KiB of 16-byte records per direction)
   static constexpr int tw_src(int p) {
-    return pos(p) >= LOGN - LPT ? TW_UNIFORM : (pos(p) >= 6 ? TW_WAVE : (pos(p) > 0 ? TW_LDS : TW_REGS));
+    return pos(p) >= LOGN - LPT ? TW_UNIFORM
+         : (pos(p) >= 6 ? TW_WAVE : (pos(p) > 0 ? (stage_end(p) <= LDS_TW_MAX_STAGE ? TW_LDS : TW_VEC) : TW_REGS));
   }
   static constexpr int lds_tw_lo() {                 // first table index kept in LDS
     for (int p = 0; p < PHASES; ++p) if (tw_src(p) == TW_LDS) return 1 << stage_begin(p);

@@ -506,6 +506,7 @@ static hipError_t launch_nttf_e(const tn_plan* p, int mode, const void* in, void
     case 10: return launch_nttf_t<E, 10, fused_lpt(10), LAZY>(p, mode, in, out, batch, s);
     case 11: return launch_nttf_t<E, 11, fused_lpt(11), LAZY>(p, mode, in, out, batch, s);
     case 12: return launch_nttf_t<E, 12, fused_lpt(12), LAZY>(p, mode, in, out, batch, s);
+    case 13: return launch_nttf_t<E, 13, fused_lpt(13), LAZY>(p, mode, in, out, batch, s);
     default: return hipErrorInvalidValue;
   }
 #endif
@@ -567,6 +568,7 @@ static hipError_t launch_fused_e(const tn_plan* p, const void* a, const void* b,
     case 10: return launch_fused_t<E, 10, fused_lpt(10), LAZY>(p, a, b, c, batch, s, cyclic);
     case 11: return launch_fused_t<E, 11, fused_lpt(11), LAZY>(p, a, b, c, batch, s, cyclic);
     case 12: return launch_fused_t<E, 12, fused_lpt(12), LAZY>(p, a, b, c, batch, s, cyclic);
+    case 13: return launch_fused_t<E, 13, fused_lpt(13), LAZY>(p, a, b, c, batch, s, cyclic);
     default: return hipErrorInvalidValue;
   }
 #endif
@@ -652,14 +654,17 @@ __device__ __forceinline__ void cg_butterfly_lazy(u64 left, u64 right, Tw64 w, c
 
 // Lane-steps one thread runs per stage: workgroups have n/2/GROUP threads up to 1024 (launch_cg_t); beyond that a thread
 // takes several (n = 4096 / GROUP = 1: two)
-template <typename E, int GROUP> struct CgShape {
-  static constexpr int MAXN = sizeof(E) == 8 ? 4096 : 8192;
+// BIG: the n = 8192 instantiation for 64-bit lanes (twice the lane-steps and pairs per thread; own kernels so that the
+// n <= 4096 ones keep their register budget)
+template <typename E, int GROUP, bool BIG = false> struct CgShape {
+  static constexpr int MAXN = (sizeof(E) == 8 && !BIG) ? 4096 : 8192;
   static constexpr int ITERS = (MAXN / 2 / GROUP) > 1024 ? (MAXN / 2 / GROUP) / 1024 : 1;
   static constexpr int KEEP = GROUP * ITERS;           // pairs of A^ one thread holds for the pointwise product
   static constexpr int THREADS_MAX = (MAXN / 2 / GROUP) > 1024 ? 1024 : (MAXN / 2 / GROUP);
   // waves per SIMD the register allocator leaves room for = what two workgroups per CU (the LDS limit) amount to:
   // 8 for 1024-thread workgroups (<= 64 VGPRs), 4 for 512, 2 for 256 (GROUP = 8 at 64-bit: 8 butterflies and 8 pairs of A^ per thread)
-  static constexpr int MIN_WAVES = 2 * THREADS_MAX / 256 < 1 ? 1 : 2 * THREADS_MAX / 256;
+  // (BIG: 128 KiB of LDS per workgroup, one workgroup per CU)
+  static constexpr int MIN_WAVES = BIG ? (THREADS_MAX / 256 < 1 ? 1 : THREADS_MAX / 256) : (2 * THREADS_MAX / 256 < 1 ? 1 : 2 * THREADS_MAX / 256);
 };
 
 // One CG transform in LDS: src holds the bit-reversed input; log2(n) stages
@@ -667,12 +672,12 @@ template <typename E, int GROUP> struct CgShape {
 // result.  (cg_ntt.py:49-64.)  If trace != nullptr every stage's output is
 // also written there ([logn][n]).  The geometry is constant: a thread's read and write addresses are the same in
 // every stage and are computed once.  LAZYB: lazy butterflies (cg_butterfly_lazy), else canonical ones.
-template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool LAZYB>
+template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool LAZYB, bool BIG>
 __device__ E* cg_stages(E* src, E* dst, const typename TwOf<E>::type* __restrict__ omega_tab, u32 n, u32 logn,
                         const Arith<E>& ar, E* trace) {
   typedef CgMap<E, GROUP, LAYOUT> M;
   typedef CgPair<E> Pair;
-  constexpr int ITERS = CgShape<E, GROUP>::ITERS;
+  constexpr int ITERS = CgShape<E, GROUP, BIG>::ITERS;
   const u32 pairs = n >> 1;
   u32 rd[ITERS], wlo[ITERS], whi[ITERS];
 #pragma unroll
@@ -757,8 +762,8 @@ __device__ void cg_store_out(E* __restrict__ out, const E* r, u32 n, const typen
 // two workgroups per CU at n = 4096 / 64-bit): thread t keeps coefficients t + k blockDim and t + k blockDim + n/2,
 // k < CgShape::KEEP.
 constexpr int CG_MODE_LAZY = 0x100;   // or-ed into the kernel's mode: lazy butterflies allowed where no trace is taken (h_cg_lazy_ok)
-template <typename E, int GROUP, int LAYOUT, bool SPLIT>
-__global__ void __launch_bounds__((CgShape<E, GROUP>::THREADS_MAX), (CgShape<E, GROUP>::MIN_WAVES))
+template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool BIG>
+__global__ void __launch_bounds__((CgShape<E, GROUP, BIG>::THREADS_MAX), (CgShape<E, GROUP, BIG>::MIN_WAVES))
 cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* trace, u32 batch) {
   typedef CgMap<E, GROUP, LAYOUT> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
@@ -772,8 +777,8 @@ cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __re
   const bool lazy = LZ && (mode_flags & CG_MODE_LAZY) && !trace;
   // run one transform: lazy stages where allowed, canonical ones otherwise (always when tracing)
   auto stages = [&](E* src, E* dst, const typename TwOf<E>::type* tab, E* tr) -> E* {
-    if constexpr (LZ) { if (lazy) return cg_stages<E, GROUP, LAYOUT, SPLIT, LZ>(src, dst, tab, n, logn, ar, nullptr); }
-    return cg_stages<E, GROUP, LAYOUT, SPLIT, false>(src, dst, tab, n, logn, ar, tr);
+    if constexpr (LZ) { if (lazy) return cg_stages<E, GROUP, LAYOUT, SPLIT, LZ, BIG>(src, dst, tab, n, logn, ar, nullptr); }
+    return cg_stages<E, GROUP, LAYOUT, SPLIT, false, BIG>(src, dst, tab, n, logn, ar, tr);
   };
   for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
     const size_t off = (size_t)row * n;
@@ -793,7 +798,7 @@ cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __re
       cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, twist, n, logn, ar);                      // :82
       E* ra = stages(p0, p1, pv.omega_pow, nullptr);                                              // :86
       // keep A^ in registers: the pairs this thread will need for the pointwise product (t, t + n/2)
-      constexpr int KEEP = CgShape<E, GROUP>::KEEP;                // >= (n/2) / blockDim for every launch shape (launch_cg_t)
+      constexpr int KEEP = CgShape<E, GROUP, BIG>::KEEP;                // >= (n/2) / blockDim for every launch shape (launch_cg_t)
       E ka_lo[KEEP], ka_hi[KEEP];
 #pragma unroll
       for (int k = 0; k < KEEP; ++k) {
@@ -827,13 +832,13 @@ cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __re
   }
 }
 
-template <typename E, int GROUP, int LAYOUT, bool SPLIT>
+template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool BIG = false>
 static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
                               hipStream_t s) {
   typedef CgMap<E, GROUP, LAYOUT> M;
   const u32 span = (M::span(p->n) + 3u) & ~3u;
   const size_t lds_bytes = (size_t)2 * span * sizeof(E);
-  auto kern = cg_kernel<E, GROUP, LAYOUT, SPLIT>;
+  auto kern = cg_kernel<E, GROUP, LAYOUT, SPLIT, BIG>;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -841,9 +846,9 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
   }
   // one lane-step per thread and stage: n/2/GROUP threads, capped (then a thread takes CgShape::ITERS lane-steps)
   u32 threads = p->n / 2 / GROUP;
-  threads = threads < 64 ? 64 : (threads > (u32)CgShape<E, GROUP>::THREADS_MAX ? (u32)CgShape<E, GROUP>::THREADS_MAX : threads);
-  if ((p->n / 2 / GROUP + threads - 1) / threads > (u32)CgShape<E, GROUP>::ITERS ||
-      (p->n / 2 + threads - 1) / threads > (u32)CgShape<E, GROUP>::KEEP) return hipErrorInvalidValue;
+  threads = threads < 64 ? 64 : (threads > (u32)CgShape<E, GROUP, BIG>::THREADS_MAX ? (u32)CgShape<E, GROUP, BIG>::THREADS_MAX : threads);
+  if ((p->n / 2 / GROUP + threads - 1) / threads > (u32)CgShape<E, GROUP, BIG>::ITERS ||
+      (p->n / 2 + threads - 1) / threads > (u32)CgShape<E, GROUP, BIG>::KEEP) return hipErrorInvalidValue;
   if (SPLIT && p->cg_lazy) mode |= CG_MODE_LAZY;
   const u32 grid = (u32)(batch < (size_t)1 << 20 ? batch : (size_t)1 << 20);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, make_view<E>(p), mode, (const E*)a, (const E*)b, (E*)out,
@@ -854,6 +859,17 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
 template <typename E, int LAYOUT, bool SPLIT>
 static hipError_t launch_cg_l(const tn_plan* p, int mode, int group, const void* a, const void* b, void* out,
                               void* trace, size_t batch, hipStream_t s) {
+  if constexpr (sizeof(E) == 8 && LAYOUT == CG_LINEAR) {
+    if (p->n > 4096) {                                            // n = 8192 at 64-bit lanes: the BIG kernels (linear layout only)
+      switch (group) {
+        case 1: return launch_cg_t<E, 1, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
+        case 2: return launch_cg_t<E, 2, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
+        case 4: return launch_cg_t<E, 4, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
+        case 8: return launch_cg_t<E, 8, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
+        default: return hipErrorInvalidValue;
+      }
+    }
+  }
   switch (group) {
     case 1: return launch_cg_t<E, 1, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
     case 2: return launch_cg_t<E, 2, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
@@ -868,6 +884,7 @@ template <typename E, bool SPLIT>
 static hipError_t launch_cg_e(const tn_plan* p, int mode, int group, int layout, const void* a, const void* b, void* out,
                               void* trace, size_t batch, hipStream_t s) {
   if (p->n < 64 || (group == 1 && layout == CG_PADDED)) layout = layout == CG_SWIZZLED && p->n >= 64 ? layout : CG_LINEAR;
+  if (sizeof(E) == 8 && p->n > 4096) layout = CG_LINEAR;              // the layout only matters to the conflict sweep (n = 4096): same bits
   if (p->n < (u32)(4 * group)) group = 1;                               // tiny n: the grouped store pairs assume n >= 4 GROUP
   switch (layout) {
     case CG_LINEAR: return launch_cg_l<E, CG_LINEAR, SPLIT>(p, mode, group, a, b, out, trace, batch, s);

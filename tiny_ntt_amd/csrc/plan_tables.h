@@ -172,6 +172,7 @@ inline bool h_split_sched_ok(u32 logn, int k, u64 c) {
     case 10: return h_split_sched_replay<FusedCfg<u64, 10, fused_lpt(10)>>(k, c);
     case 11: return h_split_sched_replay<FusedCfg<u64, 11, fused_lpt(11)>>(k, c);
     case 12: return h_split_sched_replay<FusedCfg<u64, 12, fused_lpt(12)>>(k, c);
+    case 13: return h_split_sched_replay<FusedCfg<u64, 13, fused_lpt(13)>>(k, c);
     default: return false;
   }
 }
