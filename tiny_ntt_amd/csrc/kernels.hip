@@ -264,14 +264,10 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     const u32 zero = opaque_zero();
     const u32 tl = opaque_copy(tau);         // thread index for global addressing within this row (see opaque_copy)
     // one thread determines the next row now; everyone reads the answer after a's transform (barriers in between)
-    if (left) {
-      --left;
-      if (tau == 0) *lds_next = row + 1;
-    } else {
-      left = chunk - 1;
-      chunk_id += gridDim.x;
-      if (tau == 0) *lds_next = (sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id) * chunk;
-    }
+    const bool in_chunk = left != 0;                       // workgroup-uniform bookkeeping, kept on the scalar unit
+    left = wave_uniform(in_chunk ? left - 1 : chunk - 1);
+    chunk_id = wave_uniform(in_chunk ? chunk_id : chunk_id + gridDim.x);
+    if (tau == 0) *lds_next = in_chunk ? row + 1 : (sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id) * chunk;
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
     TN_MARK("loop_top");
