@@ -24,9 +24,6 @@
 #include <type_traits>
 #include "modarith.h"
 
-#ifndef TN_BFLY_GROUP
-#define TN_BFLY_GROUP 0          // >0: scheduling fence after every TN_BFLY_GROUP butterflies of a stage (bounds the temporaries in flight)
-#endif
 // Timing-ablation switch (developer experiments only; results are wrong when set).
 #ifndef TN_ABL_UNIFORM_TW
 #define TN_ABL_UNIFORM_TW 0      // 1: every thread uses the phase-0 (wave-uniform) twiddle indices -> no vector twiddle loads
@@ -442,27 +439,10 @@ TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename 
   });
 }
 
-// ... only those of stages [S0, S1) of the last phase
-template <typename E, typename Cfg, int S0, int S1>
-TN_HD void tw_prefetch_part(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
-  constexpr int PH = Cfg::PHASES - 1;
-  if (Cfg::tw_src(PH) != Cfg::TW_REGS) return;
-  const u32 thi = Cfg::thi(PH, tau);
-  static_for<S0, S1>([&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
-#pragma unroll
-    for (int g = 0; g < Cfg::pre_count(s); ++g)
-      pre[Cfg::pre_off(s) + g] = glob[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g];
-  });
-}
 template <typename E, typename Cfg>
 TN_HD void tw_prefetch(typename TwOf<E>::type (&pre)[Cfg::NPRE], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
   tw_prefetch_raw<E, Cfg>(pre, tau, glob);
 }
-
-// ordinal of the butterfly whose "u" is register r among those of its stage (bit bpos of r is clear)
-constexpr int bfly_index(int r, int bpos) { return ((r >> (bpos + 1)) << bpos) | (r & ((1 << bpos) - 1)); }
 
 // ---------------------------------------------------------------------------
 // One forward phase on a thread's registers.
@@ -485,7 +465,6 @@ TN_HD void fwd_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
       if constexpr (!(r & (1 << bpos))) {
         const Tw w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
         Pol::template ct<SO::fwd_k(s, r)>(x[r], x[r | (1 << bpos)], w, ar);
-        if constexpr (TN_BFLY_GROUP > 0 && bfly_index(r, bpos) % TN_BFLY_GROUP == TN_BFLY_GROUP - 1) sched_fence();
       }
     });
   });
@@ -514,7 +493,6 @@ TN_HD void inv_phase(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw, const Arith<E
           const Tw w = tw_get<E, Cfg, PH, s>(tw, thi, r >> (bpos + 1));
           Pol::template gs<BND>(x[r], x[r | (1 << bpos)], w, ar);
         }
-        if constexpr (TN_BFLY_GROUP > 0 && bfly_index(r, bpos) % TN_BFLY_GROUP == TN_BFLY_GROUP - 1) sched_fence();
       }
     });
   });

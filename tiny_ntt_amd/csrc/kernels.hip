@@ -3,17 +3,18 @@
 //  polymul_fused_kernel : K6, the throughput path.  Persistent workgroups, one
 //      polynomial pair at a time; coefficients live in VGPRs (2^LPT per thread), the
 //      log2(n) radix-2 stages run as ceil(log2 n / LPT) register phases with LDS
-//      transposes between them (XOR-swizzled at n = 4096 / 64-bit lanes, padded
-//      otherwise); psi-twist and n^-1 folded into the twiddles (fused_core.h); the
-//      same kernel on the x^n - 1 twiddle tables is the cyclic product.
+//      transposes between them (padded, bank-conflict-free images addressed as
+//      base + immediate offset); psi-twist and n^-1 folded into the twiddles
+//      (fused_core.h); the same kernel on the x^n - 1 twiddle tables is the cyclic product.
 //      HBM traffic per product = read a, read b, write c.
 //  ntt_fused_kernel     : the standalone transforms (twist+forward, cg_ntt, cg_intt)
 //      on the same machinery, natural order in and out.
 //  cg_kernel            : K1-K5/K7, the reference's own constant-geometry
-//      dataflow (cg_ntt.py:49-64) held in LDS ping-pong buffers, canonical
-//      arithmetic at every step so each stage's output equals the reference's
-//      list `A` (trace parity); GROUP = butterflies issued per lane-step
-//      (8 = cg_ntt_8butterfly.py), PAD = conflict-free LDS image.
+//      dataflow (cg_ntt.py:49-64) held in two LDS ping-pong images; canonical
+//      arithmetic at every step when a trace is taken, so each stage's output
+//      equals the reference's list `A`; GROUP = butterflies issued per lane-step
+//      (8 = cg_ntt_8butterfly.py), LAYOUT = linear / padded / XOR-swizzled image
+//      (the LDS-bank-conflict sweep of BASELINE config 5).
 //  fill_lcg_kernel / checksum_kernel : the reference benchmark's input
 //      generator and digest (benchmark_ntt_60bit.cpp:79-87,182-188), on device.
 #include <hip/hip_runtime.h>
@@ -47,10 +48,6 @@
 #endif
 #ifndef TN_KARG_ARITH
 #define TN_KARG_ARITH 1          // 1: the product kernel reads its arithmetic constants and scalar twiddles per phase (kernarg_arith)
-#endif
-#ifndef TN_INV_PREFETCH
-#define TN_INV_PREFETCH 0        // thread-private twiddles of the inverse's first phase: 0 all requested before the pointwise product,
-                                 // 1 only those of its first stage (the rest after the product, when b's registers are free), 2 all after
 #endif
 #ifndef TN_SHARE_MID_TW
 #define TN_SHARE_MID_TW 1        // 1: ... and the phase before it (twiddles staged in LDS) likewise: a: ph 0-1, b: ph 0-1, a: ph 2, b: ph 2, b: ph 3, a: ph 3
@@ -317,23 +314,10 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     }
     // the inverse starts with the thread-private phase: request its twiddles before the product
     Tw pre[Cfg::NPRE];
-#if TN_INV_PREFETCH == 0
     tw_prefetch<E, Cfg>(pre, tl, tab_inv);
-#elif TN_INV_PREFETCH == 1
-    tw_prefetch_part<E, Cfg, Cfg::LOGN - 1, Cfg::LOGN>(pre, tl, tab_inv);       // the stage the inverse starts with
-#endif
     TN_MARK("pointwise");
     pointwise<E, Cfg, Pol>(xa, xb, ar);
     TN_MARK("after_pointwise");
-#if TN_INV_PREFETCH == 1
-    sched_fence();
-    tw_prefetch_part<E, Cfg, Cfg::stage_begin(Cfg::PHASES - 1), Cfg::LOGN - 1>(pre, tl, tab_inv);
-    sched_fence();
-#elif TN_INV_PREFETCH == 2
-    sched_fence();
-    tw_prefetch<E, Cfg>(pre, tl, tab_inv);
-    sched_fence();
-#endif
     const TwRefs<E> twi = {tab_inv, lds_inv, pre, nullptr, zero};
     inverse_all<E, Cfg, Pol, KARG>(xa, tau, twi, ar, lds, [&]() {
       // next row's first operand -> the registers that held b.  Unconditional (after the last row this row's a is read
