@@ -270,3 +270,23 @@ def test_overlapping_output_is_rejected_and_many_streams_stay_correct(eng):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, ref)
+
+
+def test_omega_only_plan_at_the_largest_32bit_size(eng, oracle):
+    """n = 8192 with the 23-bit modulus has no negacyclic psi (2n does not divide q - 1) but a cyclic omega (n | q - 1): the
+    omega-only plan runs the constant-geometry kernels with four lane-steps per thread and stage (CgShape::ITERS)."""
+    n, q = 8192, 8380417
+    g = next(x for x in range(2, 50) if pow(x, (q - 1) // 2, q) == q - 1)          # a quadratic non-residue
+    omega = pow(g, (q - 1) // n, q)
+    assert pow(omega, n // 2, q) == q - 1
+    plan = eng.get_omega_plan(n, q, omega)
+    rng = np.random.default_rng(13)
+    x = rng.integers(0, q, (5, n), dtype=np.uint64).astype(plan.dtype)
+    for v in ("cg", "cg8", "cg4_swizzled", "cg2_padded"):
+        X = plan.ntt_forward(x, variant=v)
+        for r in range(5):
+            assert np.array_equal(X[r].astype(np.uint64), oracle.cg_ntt(x[r].astype(np.uint64), omega, q)), (v, r)
+        assert np.array_equal(plan.ntt_inverse(X, variant=v), x), v
+    out, trace = plan.ntt_forward_trace(x[0], variant="cg")
+    ref, rtrace = oracle.cg_ntt(x[0].astype(np.uint64), omega, q, trace=True)
+    assert np.array_equal(out.astype(np.uint64), ref) and np.array_equal(trace.astype(np.uint64), rtrace)
