@@ -424,19 +424,26 @@ TN_HD void tw_fetch_mid(typename TwOf<E>::type (&mid)[Cfg::R], u32 tau, const ty
   });
 }
 
-// Fetch the calling thread's last-phase twiddles into registers (issued ahead of their use).
-template <typename E, typename Cfg>
-TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+// Fetch the calling thread's last-phase twiddles of stages [S0, S1) into registers (issued ahead of their use).
+template <typename E, typename Cfg, int S0, int S1>
+TN_HD void tw_prefetch_stages(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
   constexpr int PH = Cfg::PHASES - 1;
   if (Cfg::tw_src(PH) != Cfg::TW_REGS) return;
   const u32 thi = Cfg::thi(PH, tau);
-  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
+  static_for<S0, S1>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    // byte offset computed in 32 bits: the access is then "uniform table base + one 32-bit thread offset + immediate"
+    // (a 64-bit index makes every record's address a VGPR pair that lives across the persistent row loop)
+    const u32 off = ((1u << s) + (thi << (Cfg::LPT - bpos - 1))) * (u32)sizeof(typename TwOf<E>::type);
+    const typename TwOf<E>::type* base = reinterpret_cast<const typename TwOf<E>::type*>(reinterpret_cast<const char*>(glob) + off);
 #pragma unroll
-    for (int g = 0; g < Cfg::pre_count(s); ++g)
-      pre[Cfg::pre_off(s) + g] = glob[(1u << s) + (thi << (Cfg::LPT - bpos - 1)) + (u32)g];
+    for (int g = 0; g < Cfg::pre_count(s); ++g) pre[Cfg::pre_off(s) + g] = base[g];
   });
+}
+template <typename E, typename Cfg>
+TN_HD void tw_prefetch_raw(typename TwOf<E>::type* pre, u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+  tw_prefetch_stages<E, Cfg, Cfg::stage_begin(Cfg::PHASES - 1), Cfg::LOGN>(pre, tau, glob);
 }
 
 template <typename E, typename Cfg>

@@ -49,6 +49,11 @@
 #ifndef TN_KARG_ARITH
 #define TN_KARG_ARITH 1          // 1: the product kernel reads its arithmetic constants and scalar twiddles per phase (kernarg_arith)
 #endif
+#ifndef TN_RESIDENT_TW
+#define TN_RESIDENT_TW 1         // 1: the thread-private twiddles of the LAST forward stage (4 of the 7 records of the last phase; they do
+                                 //    not depend on the row) stay in registers across rows of the persistent loop: 64 fewer bytes per
+                                 //    thread and row from L2, and the registers were free (99 of 128 VGPRs in use)
+#endif
 #ifndef TN_SHARE_MID_TW
 #define TN_SHARE_MID_TW 1        // 1: ... and the phase before it (twiddles staged in LDS) likewise: a: ph 0-1, b: ph 0-1, a: ph 2, b: ph 2, b: ph 3, a: ph 3
 #endif
@@ -119,7 +124,7 @@ __device__ __forceinline__ const Arith<E>& kernarg_arith(u32 zero) {
 // Forward transform, phases [P0, P1).  The thread-private twiddles of the last phase live in tw.pre[]; with `fetch_pre` they
 // are requested from L2 just before the transpose that precedes that phase, so their latency hides behind it.
 // KARG: take the arithmetic constants and the scalar twiddles of each phase through a fresh opaque zero (see kernarg_arith).
-template <typename E, typename Cfg, typename Pol, int P0, int P1, bool KARG = false>
+template <typename E, typename Cfg, typename Pol, int P0, int P1, bool KARG = false, int PRE_END = Cfg::LOGN>
 __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw_in, const Arith<E>& ar_in, E* lds, bool fetch_pre,
                                               u32 tau_g) {      // tau_g: the thread index again, for global addressing (opaque_copy)
   static_for<P0, P1>([&](auto p_) {
@@ -133,7 +138,7 @@ __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwR
     if constexpr (p == Cfg::PHASES - 2) {
       if (fetch_pre) {
         sched_fence();                 // request the last phase's private twiddles; they fly during the transpose
-        tw_prefetch_raw<E, Cfg>(tw.pre, tau_g, tw.glob);
+        tw_prefetch_stages<E, Cfg, Cfg::stage_begin(Cfg::PHASES - 1), PRE_END>(tw.pre, tau_g, tw.glob);   // (stages >= PRE_END: resident)
         sched_fence();
       }
     }
@@ -250,6 +255,10 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // (first iteration: nothing to store yet -> the zero-initialised registers are written to this
   //  row's own slot, which the same thread overwrites with the real result one iteration later;
   //  keeping the store unconditional keeps the loop top branch-free so the ordering below holds)
+  // last forward phase's thread-private twiddles, shared by a and b; those of the last stage are loaded once per workgroup
+  constexpr int PRE_END = (TN_RESIDENT_TW && Cfg::stage_end(Cfg::PHASES - 1) - Cfg::stage_begin(Cfg::PHASES - 1) >= 2) ? Cfg::LOGN - 1 : Cfg::LOGN;
+  Tw prf[Cfg::NPRE];
+  tw_prefetch_stages<E, Cfg, PRE_END, Cfg::LOGN>(prf, tau, tab_fwd);
   u32 prev = row;
   bool have_c = false;
 #pragma unroll
@@ -287,7 +296,6 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     constexpr int PM = Cfg::PHASES >= 3 ? Cfg::PHASES - 2 : 0;
     constexpr bool SHARE2 = SHARE && TN_SHARE_MID_TW && Cfg::PHASES >= 3 && Cfg::tw_src(PM) == Cfg::TW_LDS &&
                             Cfg::stage_end(PM) - Cfg::stage_begin(PM) == Cfg::LPT;
-    Tw prf[Cfg::NPRE];                       // last forward phase's thread-private twiddles, shared by a and b
     const TwRefs<E> twf = {tab_fwd, lds_fwd, prf, nullptr, zero};
     // A^ stays in registers while b is transformed (no spills at 128 VGPRs since the round-1 trims)
     if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM, KARG>(xa, tau, twf, ar, lds, false, tl);
@@ -302,11 +310,11 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
       tw_fetch_mid<E, Cfg, PM>(mid, tau, lds_fwd);
       const TwRefs<E> twm = {tab_fwd, lds_fwd, prf, mid, zero};
       forward_range<E, Cfg, Pol, PM, PM + 1, KARG>(xa, tau, twm, ar, lds, false, tl);
-      forward_range<E, Cfg, Pol, PM, PM + 1, KARG>(xb, tau, twm, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, PM, PM + 1, KARG, PRE_END>(xb, tau, twm, ar, lds, true, tl);
       forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES, KARG>(xb, tau, twf, ar, lds, false, tl);
       forward_range<E, Cfg, Pol, PM + 1, Cfg::PHASES, KARG>(xa, tau, twf, ar, lds, false, tl);
     } else if constexpr (SHARE) {
-      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1, KARG>(xb, tau, twf, ar, lds, true, tl);
+      forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1, KARG, PRE_END>(xb, tau, twf, ar, lds, true, tl);
       forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES, KARG>(xb, tau, twf, ar, lds, false, tl);
       forward_range<E, Cfg, Pol, Cfg::PHASES - 1, Cfg::PHASES, KARG>(xa, tau, twf, ar, lds, false, tl);
     } else {
@@ -643,8 +651,9 @@ template <typename E, int GROUP, bool BIG = false> struct CgShape {
   static constexpr int THREADS_MAX = (MAXN / 2 / GROUP) > 1024 ? 1024 : (MAXN / 2 / GROUP);
   // waves per SIMD the register allocator leaves room for = what two workgroups per CU (the LDS limit) amount to:
   // 8 for 1024-thread workgroups (<= 64 VGPRs), 4 for 512, 2 for 256 (GROUP = 8 at 64-bit: 8 butterflies and 8 pairs of A^ per thread)
-  // (BIG: 128 KiB of LDS per workgroup, one workgroup per CU)
-  static constexpr int MIN_WAVES = BIG ? (THREADS_MAX / 256 < 1 ? 1 : THREADS_MAX / 256) : (2 * THREADS_MAX / 256 < 1 ? 1 : 2 * THREADS_MAX / 256);
+  // (BIG and the 32-bit kernels, whose per-thread arrays are sized for n = 8192: one workgroup's worth, no spills)
+  static constexpr int MIN_WAVES = (BIG || sizeof(E) == 4) ? (THREADS_MAX / 256 < 1 ? 1 : THREADS_MAX / 256)
+                                                           : (2 * THREADS_MAX / 256 < 1 ? 1 : 2 * THREADS_MAX / 256);
 };
 
 // One CG transform in LDS: src holds the bit-reversed input; log2(n) stages
