@@ -201,6 +201,9 @@ class Emu:
         L.emu_pw_fast_ok.argtypes = [u64]; L.emu_pw_fast_ok.restype = ctypes.c_int
         L.emu_pointwise_lazy64.argtypes = [u64, u64, u64]; L.emu_pointwise_lazy64.restype = u64
         L.emu_fold32.argtypes = [u32, u32]; L.emu_fold32.restype = u32
+        L.emu_mul_sp_acc.argtypes = [u64, u64, u64, u64]; L.emu_mul_sp_acc.restype = u64
+        L.emu_split_sched_ok.argtypes = [u32, u64]; L.emu_split_sched_ok.restype = ctypes.c_int
+        L.emu_split_sched_stat.argtypes = [ctypes.c_int, ctypes.c_int]; L.emu_split_sched_stat.restype = ctypes.c_long
 
     def fused(self, n, q, psi, a, b, canonical=False, cyclic=False):
         a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)

@@ -119,6 +119,31 @@ def test_pointwise_lazy64_any_words(emu):
         assert emu.lib.emu_pw_fast_ok(q) == 0, q
 
 
+def test_split_constant_product_is_exact_and_bounded(emu):
+    """mul_sp_acc (modarith.h): u + a*w as six 32x32+64 multiply-adds on the split record {wlo, whi, xlo, xhi}.  For ANY
+    64-bit a the result is the integer u + t' with t' == a*w (mod q) and t' below the bound the schedule uses
+    (2^(k+1) + (a >> 32) 2^p + 2^(k+1) + 2^32 * 2c), for the reference's modulus and other admissible q = 2^k - c."""
+    rnd = random.Random(44)
+    for q in (PARAMS["P4096_60"][1], 2 ** 57 - 2 ** 11 + 1 - 0, 2 ** 52 - 2 ** 13 * 5 + 1, 2 ** 47 - 2 ** 9 * 3 + 1):
+        k = q.bit_length(); c = 2 ** k - q; p = k - 31
+        ws = [0, 1, 2, q - 1, q - 2, q // 2, 2 ** p - 1, 2 ** p, 2 ** (k - 1)] + [rnd.randrange(q) for _ in range(200)]
+        avals = EDGE64 + [q - 1, q, 2 ** k - 1, 2 ** k, 2 ** 64 - 2 ** 32, 2 ** 32 * (2 ** 32 - 1) + 1] + [rnd.randrange(2 ** 64) for _ in range(200)]
+        for w in ws:
+            for a in avals[:30] if w > 2 else avals:
+                a %= 2 ** 64
+                tmax = 2 ** (k + 1) + (a >> 32) * 2 ** p + 2 ** (k + 1) + 2 ** 32 * 2 * c
+                for u in (0, 1, 2 ** 64 - 1 - tmax, rnd.randrange(2 ** 64 - tmax)):
+                    r = emu.lib.emu_mul_sp_acc(u, a, w, q)
+                    assert r >= u and r - u < tmax and (r - u - a * w) % q == 0, (q, u, a, w)
+    # the bound schedule of every fused shape replays exactly for the reference's modulus, and folds stay rare
+    for logn in (8, 9, 10, 11, 12, 13):
+        assert emu.lib.emu_split_sched_ok(logn, PARAMS["P4096_60"][1]) == 1
+        fwd, inv, fout = (emu.lib.emu_split_sched_stat(logn, i) for i in range(3))
+        assert fwd <= 2 * logn and inv <= 3 * logn and fout <= 14 * 4096, (logn, fwd, inv, fout)
+    assert emu.lib.emu_split_sched_ok(12, 2 ** 60 - 2 ** 30 + 1) == 0          # c too large: not lazy
+    assert emu.lib.emu_split_sched_ok(12, 2 ** 41 - 21 * 2 ** 13 + 1) == 0      # 2^33 c is not << 2^k
+
+
 def test_barrett64_boundaries(emu):
     rnd = random.Random(3)
     for q in (PARAMS["P4096_60"][1], 4611686018326724609, 2 ** 61 - 1, 1099511627689):
