@@ -406,7 +406,24 @@ TN_HD typename TwOf<E>::type tw_get(const TwRefs<E>& t, u32 thi, int g) {
     if (t.mid) return t.mid[(1 << (S_ - Cfg::stage_begin(PH))) - 1 + g];      // stage i of a full phase has 2^i twiddles, starting at 2^i - 1
     return t.lds[idx - Cfg::lds_tw_lo()];
   }
+  if (Cfg::tw_src(PH) == Cfg::TW_VEC && t.mid) return t.mid[(1 << (S_ - Cfg::stage_begin(PH))) - 1 + g];   // prefetched (tw_fetch_vec)
   return t.glob[idx + t.zero];
+}
+
+// The calling thread's twiddles of a FULL vector-loaded phase PH (TW_VEC), requested from the L2-resident table into
+// registers ahead of the transpose that precedes the phase (same register layout as tw_fetch_mid).
+template <typename E, typename Cfg, int PH>
+TN_HD void tw_fetch_vec(typename TwOf<E>::type (&mid)[Cfg::R], u32 tau, const typename TwOf<E>::type* __restrict__ glob) {
+  const u32 thi = Cfg::thi(PH, tau);
+  static_for<Cfg::stage_begin(PH), Cfg::stage_end(PH)>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int bpos = (Cfg::LOGN - 1 - s) - Cfg::pos(PH);
+    constexpr int cnt = Cfg::R >> (bpos + 1), off = (1 << (s - Cfg::stage_begin(PH))) - 1;
+    const u32 boff = ((1u << s) + (thi << (Cfg::LPT - bpos - 1))) * (u32)sizeof(typename TwOf<E>::type);
+    const typename TwOf<E>::type* base = reinterpret_cast<const typename TwOf<E>::type*>(reinterpret_cast<const char*>(glob) + boff);
+#pragma unroll
+    for (int g = 0; g < cnt; ++g) mid[off + g] = base[g];
+  });
 }
 
 // The calling thread's twiddles of an LDS-sourced FULL phase PH (LPT stages: 1 + 2 + ... = R - 1 of them), read into

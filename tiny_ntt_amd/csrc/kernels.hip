@@ -127,11 +127,14 @@ __device__ __forceinline__ const Arith<E>& kernarg_arith(u32 zero) {
 template <typename E, typename Cfg, typename Pol, int P0, int P1, bool KARG = false, int PRE_END = Cfg::LOGN>
 __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw_in, const Arith<E>& ar_in, E* lds, bool fetch_pre,
                                               u32 tau_g) {      // tau_g: the thread index again, for global addressing (opaque_copy)
+  typename TwOf<E>::type vec[Cfg::R];        // twiddles of a vector-loaded phase (n = 8192), requested one transpose ahead
   static_for<P0, P1>([&](auto p_) {
     constexpr int p = decltype(p_)::value;
+    constexpr bool FULL = Cfg::stage_end(p) - Cfg::stage_begin(p) == Cfg::LPT;
     TN_MARK("fwd_phase");
     TwRefs<E> tw = tw_in;
     if constexpr (KARG) tw.zero = opaque_zero();
+    if constexpr (Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p > P0) tw.mid = vec;
     const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("fwd_other");
@@ -139,6 +142,14 @@ __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwR
       if (fetch_pre) {
         sched_fence();                 // request the last phase's private twiddles; they fly during the transpose
         tw_prefetch_stages<E, Cfg, Cfg::stage_begin(Cfg::PHASES - 1), PRE_END>(tw.pre, tau_g, tw.glob);   // (stages >= PRE_END: resident)
+        sched_fence();
+      }
+    }
+    if constexpr (p + 1 < P1) {
+      constexpr int pn = p + 1 < Cfg::PHASES ? p + 1 : p;
+      if constexpr (Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
+        sched_fence();
+        tw_fetch_vec<E, Cfg, pn>(vec, tau_g, tw.glob);
         sched_fence();
       }
     }
@@ -160,16 +171,27 @@ __device__ __forceinline__ void forward_all(E (&x)[Cfg::R], u32 tau, const typen
 template <typename E, typename Cfg, typename Pol, bool KARG = false, typename F>
 __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRefs<E>& tw_in, const Arith<E>& ar_in, E* lds,
                                             F&& after_first) {
+  typename TwOf<E>::type vec[Cfg::R];        // twiddles of a vector-loaded phase (n = 8192), requested one transpose ahead
   static_for<0, Cfg::PHASES>([&](auto i_) {
     constexpr int p = Cfg::PHASES - 1 - decltype(i_)::value;
+    constexpr bool FULL = Cfg::stage_end(p) - Cfg::stage_begin(p) == Cfg::LPT;
     TN_MARK("inv_phase");
     TwRefs<E> tw = tw_in;
     if constexpr (KARG) tw.zero = opaque_zero();
+    if constexpr (Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p < Cfg::PHASES - 1) tw.mid = vec;
     const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("inv_other");
     if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
-    if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
+    if constexpr (p > 0) {
+      constexpr int pn = p > 0 ? p - 1 : 0;
+      if constexpr (Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
+        sched_fence();
+        tw_fetch_vec<E, Cfg, pn>(vec, tau, tw.glob);
+        sched_fence();
+      }
+      exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
+    }
   });
 }
 
