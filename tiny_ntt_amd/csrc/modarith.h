@@ -192,6 +192,26 @@ struct SplitK { u32 mulp, cf; };     // 2^p  and  2^(p+32) mod q (= 2c)
 // The caller's bound schedule guarantees u + t' < 2^64 (SplitSched in fused_core.h, verified for the plan's
 // (k, c) on the host by h_split_sched_ok()).  mulp is a run-time value on purpose: with a literal 2^p the
 // compiler turns that multiply-add into a 64-bit shift and a 64-bit add (two instructions).
+#ifndef TN_SOLINAS5
+#define TN_SOLINAS5 0            // developer A/B only (profiles/r2_g_five_multiply_ab.txt): 1 = the 5-multiply form below instead of the 6
+#endif
+#if TN_SOLINAS5
+// The 5-multiply split-constant product proposed in the round-1 review, for k = 60: record {w, x = w 2^32 mod q} as plain
+// 64-bit words; a w == a0 w + a1 x is four multiply-adds into a 94-bit sum S = H2 2^32 + lo32(L2) with the carries chained
+// through the high column, and ONE fold at bit 62 (2^62 == 4c).  Fewer multiplies, but the column carries need glue: two
+// zero-extended pairs, a 64-bit add, a mask and a funnel shift; and the butterfly's "+ u" cannot ride (the fold comes after).
+TN_HD u64 mul_sp_acc(u64 u, u64 a, Tw64 t, SplitK sk) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+  const u32 w0 = (u32)t.w, w1 = (u32)(t.w >> 32), x0 = (u32)t.wp, x1 = (u32)(t.wp >> 32);
+  const u64 L1 = (u64)a0 * w0;
+  const u64 H1 = (u64)a0 * w1 + (L1 >> 32);
+  const u64 L2 = (u64)a1 * x0 + (u32)L1;
+  const u64 H2 = (u64)a1 * x1 + (H1 + (L2 >> 32));             // S < 2^94  ->  H2 < 2^62
+  const u32 top = (u32)(H2 >> 30);                               // S >> 62
+  const u64 low = ((u64)((u32)H2 & 0x3FFFFFFFu) << 32) | (u32)L2;   // S mod 2^62
+  return u + (low + (u64)top * (sk.cf << 1));                    // cf = 2c  ->  2^62 == 4c;  product < 2^62 + 2^32 4c
+}
+#else
 TN_HD u64 mul_sp_acc(u64 u, u64 a, Tw64 t, SplitK sk) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
   u64 L = (u64)a0 * (u32)t.w + u;
@@ -202,6 +222,7 @@ TN_HD u64 mul_sp_acc(u64 u, u64 a, Tw64 t, SplitK sk) {
   r = (u64)(u32)(H >> 32) * sk.cf + r;
   return r;
 }
+#endif
 TN_HD u64 mul_sp(u64 a, Tw64 t, SplitK sk) { return mul_sp_acc(0, a, t, sk); }
 
 // Two-operand Barrett (A9).  a, b in [0, q); k = bitlen(q) in [2, 62]; mu = floor(2^(2k)/q) (<= k+1 bits).
@@ -292,11 +313,14 @@ inline Tw64 h_make_tw64(u64 w, u64 q) {
   Tw64 t; t.w = w; t.wp = (u64)((((unsigned __int128)w) << 64) / q); return t;
 }
 inline Tw64 h_make_tw64_split(u64 w, u64 q, int k) {       // see mul_sp_acc
+#if TN_SOLINAS5
+  Tw64 t5; t5.w = w; t5.wp = (u64)((((unsigned __int128)w) << 32) % q); (void)k; return t5;
+#endif
   const int p = k - 31;
   const u64 x = (u64)((((unsigned __int128)w) << 32) % q), m = (((u64)1) << p) - 1;
   Tw64 t; t.w = (w & m) | ((w >> p) << 32); t.wp = (x & m) | ((x >> p) << 32); return t;
 }
-inline u64 h_split_value(Tw64 t, int k) { return (u64)(u32)t.w + ((t.w >> 32) << (k - 31)); }   // w back from its record
+inline u64 h_split_value(Tw64 t, int k) { return TN_SOLINAS5 ? t.w : (u64)(u32)t.w + ((t.w >> 32) << (k - 31)); }   // w back from its record
 inline Tw32 h_make_tw32(u64 w, u64 q) {
   Tw32 t; t.w = (u32)w; t.wp = (u32)((w << 32) / q); return t;
 }
