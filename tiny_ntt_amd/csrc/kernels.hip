@@ -46,6 +46,9 @@
 #ifndef TN_SCHED_CHUNK_BYTES
 #define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
 #endif
+#ifndef TN_SADDR
+#define TN_SADDR 1               // 1: operand rows are addressed as scalar base (+ register offset, scalar unit) + 32-bit thread offset
+#endif
 #ifndef TN_KARG_ARITH
 #define TN_KARG_ARITH 1          // 1: the product kernel reads its arithmetic constants and scalar twiddles per phase (kernarg_arith)
 #endif
@@ -197,6 +200,20 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
 
 template <typename E> struct alignas(2 * sizeof(E)) PairOf { E lo, hi; };
 
+// A global-memory pointer the compiler must keep in scalar registers (both halves through wave_uniform): the access it
+// bases is then "scalar base + 32-bit thread offset" (global_load ... v_off, s[base]) and the base arithmetic stays on
+// the scalar unit.  (The explicit address space keeps the access a global_* instruction after the integer round trip.)
+#define TN_GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ TN_GLOBAL_AS T* uniform_ptr(T* p) {
+#if TN_SADDR
+  const unsigned long long v = (unsigned long long)p;
+  return (TN_GLOBAL_AS T*)(((unsigned long long)wave_uniform((u32)(v >> 32)) << 32) | wave_uniform((u32)v));
+#else
+  return (TN_GLOBAL_AS T*)p;
+#endif
+}
+
 template <typename E, typename Cfg>
 __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 tau, int r) {
 #if TN_ABL_NO_GLOBAL
@@ -208,8 +225,8 @@ __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 ta
 #if TN_NT_STREAM
   // address = (row base + the register's offset: wave-uniform, scalar unit) + the thread's offset (ONE vector register for all
   // R accesses); written out so the compiler does not keep one vector offset per 8 KiB of row (loop invariants it then spills)
-  const E* rp = p + ((size_t)row << Cfg::LOGN) + Cfg::jidx(0, 0, r);
-  return __builtin_nontemporal_load(rp + Cfg::jidx(0, tau, 0));   // streamed once: keep L2 for the twiddle tables
+  const TN_GLOBAL_AS E* rp = uniform_ptr(p + ((size_t)row << Cfg::LOGN) + Cfg::jidx(0, 0, r));
+  return __builtin_nontemporal_load(rp + (Cfg::jidx(0, tau, 0) & (u32)(Cfg::N - 1)));   // streamed once: keep L2 for the twiddle tables
 #else
   return p[((size_t)row << Cfg::LOGN) + Cfg::jidx(0, tau, r)];
 #endif
@@ -225,7 +242,7 @@ __device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, c
 #pragma unroll
   for (int r = 0; r < Cfg::R; ++r) {
 #if TN_NT_STREAM
-    __builtin_nontemporal_store(x[r], (c + off + Cfg::jidx(0, 0, r)) + Cfg::jidx(0, tau, 0));
+    __builtin_nontemporal_store(x[r], uniform_ptr(c + off + Cfg::jidx(0, 0, r)) + (Cfg::jidx(0, tau, 0) & (u32)(Cfg::N - 1)));
 #else
     c[off + Cfg::jidx(0, tau, r)] = x[r];
 #endif
