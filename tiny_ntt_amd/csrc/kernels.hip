@@ -38,6 +38,12 @@
 #ifndef TN_FUSED_MIN_WAVES
 #define TN_FUSED_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (4 -> <= 128 VGPRs)
 #endif
+#ifndef TN_POLYMUL60_WAVES
+#define TN_POLYMUL60_WAVES 6     // the same for the benchmark-shape product kernel (n = 4096, 64-bit lanes, lazy): 6 -> <= 80 VGPRs, three
+                                 //    512-thread workgroups per CU (3 x 51,204 B of LDS).  Measured +3 % over 4 (profiles/r2_h_*): the extra
+                                 //    waves fill the issue slots the barriers and LDS round trips leave (10 % fewer cycles per launch) and the
+                                 //    power cap gives two thirds of that back as clock (2.06 -> 1.92 GHz at 1.39 kW)
+#endif
 
 #ifndef TN_DYNAMIC_ROWS
 #define TN_DYNAMIC_ROWS 1        // 1: persistent workgroups take their next row from a device counter (atomicAdd) instead of a fixed
@@ -55,7 +61,8 @@
 #ifndef TN_RESIDENT_TW
 #define TN_RESIDENT_TW 1         // 1: the thread-private twiddles of the LAST forward stage (4 of the 7 records of the last phase; they do
                                  //    not depend on the row) stay in registers across rows of the persistent loop: 64 fewer bytes per
-                                 //    thread and row from L2, and the registers were free (99 of 128 VGPRs in use)
+                                 //    thread and row from L2.  Only where the register budget is 128 (polymul_waves() <= 4): worth 0.8 %,
+                                 //    against the 3 % of the third workgroup per CU that those 16 registers would cost
 #endif
 #ifndef TN_SHARE_MID_TW
 #define TN_SHARE_MID_TW 1        // 1: ... and the phase before it (twiddles staged in LDS) likewise: a: ph 0-1, b: ph 0-1, a: ph 2, b: ph 2, b: ph 3, a: ph 3
@@ -249,8 +256,14 @@ __device__ __forceinline__ void st_result(E* __restrict__ c, u32 row, u32 tau, c
   }
 }
 
+// waves per SIMD the product kernel's register allocation leaves room for (16 coeff/thread shapes need > 128 VGPRs)
 template <typename E, int LOGN, int LPT, bool LAZY>
-__global__ void __launch_bounds__((1 << (LOGN - LPT)), (LPT >= 4 ? 2 : TN_FUSED_MIN_WAVES))   // 16 coeff/thread shapes need > 128 VGPRs
+constexpr int polymul_waves() {
+  return LPT >= 4 ? 2 : (sizeof(E) == 8 && LOGN == 12 && LAZY) ? TN_POLYMUL60_WAVES : TN_FUSED_MIN_WAVES;
+}
+
+template <typename E, int LOGN, int LPT, bool LAZY>
+__global__ void __launch_bounds__((1 << (LOGN - LPT)), (polymul_waves<E, LOGN, LPT, LAZY>()))
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
                      const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
                      E* __restrict__ c, u32 batch, u32* sched, u32 chunk) {
@@ -281,7 +294,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // top of the row and not needed until a's forward transform is done.
   E xa[Cfg::R], xb[Cfg::R];
   u32 row = blockIdx.x * chunk;
-  u32 left = chunk - 1;                     // rows still to take from the current chunk   (both workgroup-uniform: scalar registers)
+  u32 taken = 1;                            // rows taken from the current chunk           (both workgroup-uniform: scalar registers)
   u32 chunk_id = blockIdx.x;                // fixed-stride mode: the chunk being processed
   if (row < batch) {
 #pragma unroll
@@ -295,7 +308,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   //  row's own slot, which the same thread overwrites with the real result one iteration later;
   //  keeping the store unconditional keeps the loop top branch-free so the ordering below holds)
   // last forward phase's thread-private twiddles, shared by a and b; those of the last stage are loaded once per workgroup
-  constexpr int PRE_END = (TN_RESIDENT_TW && Cfg::stage_end(Cfg::PHASES - 1) - Cfg::stage_begin(Cfg::PHASES - 1) >= 2) ? Cfg::LOGN - 1 : Cfg::LOGN;
+  constexpr int PRE_END = (TN_RESIDENT_TW && polymul_waves<E, LOGN, LPT, LAZY>() <= 4 && Cfg::stage_end(Cfg::PHASES - 1) - Cfg::stage_begin(Cfg::PHASES - 1) >= 2) ? Cfg::LOGN - 1 : Cfg::LOGN;
   Tw prf[Cfg::NPRE];
   tw_prefetch_stages<E, Cfg, PRE_END, Cfg::LOGN>(prf, tau, tab_fwd);
   u32 prev = row;
@@ -309,9 +322,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     const u32 zero = opaque_zero();
     const u32 tl = opaque_copy(tau);         // thread index for global addressing within this row (see opaque_copy)
     // one thread determines the next row now; everyone reads the answer after a's transform (barriers in between)
-    const bool in_chunk = left != 0;                       // workgroup-uniform bookkeeping, kept on the scalar unit
-    left = wave_uniform(in_chunk ? left - 1 : chunk - 1);
-    chunk_id = wave_uniform(in_chunk ? chunk_id : chunk_id + gridDim.x);
+    const bool in_chunk = taken != chunk;                  // workgroup-uniform bookkeeping, kept on the scalar unit (counting up:
+    taken = in_chunk ? taken + 1 : 1;                      // a down-counter's "subtract and test the borrow" is selected as a vector op)
+    chunk_id = in_chunk ? chunk_id : chunk_id + gridDim.x;
     if (tau == 0) *lds_next = in_chunk ? row + 1 : (sched ? gridDim.x + atomicAdd(&sched[0], 1u) : chunk_id) * chunk;
     // consume this row's a (prefetched during the previous inverse) FIRST: at this point only those
     // loads are in flight, so the wait is exact; only then issue the stores of the previous row and b's loads
