@@ -30,6 +30,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.tn_version() == 100
 
 
+def test_build_id_names_the_sources_the_library_was_built_from():
+    """tn_build_id() = sha256 of every source of the library (csrc/Makefile BUILD_ID): measurements kept in profiles/ name the
+    build they belong to, so a library older than its sources (or an id older than the kernels) must not go unnoticed."""
+    import hashlib
+    d = os.path.join(ROOT, "tiny_ntt_amd", "csrc")
+    files = ["kernels.hip", "capi.cpp", "modarith.h", "fused_core.h", "plan.h", "plan_tables.h", "../../include/tinyntt.h"]
+    h = hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in files)).hexdigest()[:16]
+    assert engine.build_id() == h, "tiny_ntt_amd/lib/libtinyntt.so is stale: run make -C tiny_ntt_amd/csrc"
+
+
 def test_library_links_hip_runtime_not_the_oracle():
     import subprocess
     out = subprocess.run(["readelf", "-d", engine.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout

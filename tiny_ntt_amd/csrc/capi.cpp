@@ -38,10 +38,7 @@ struct DeviceGuard {
 
 extern "C" const char* tn_last_error(void) { return g_err.c_str(); }
 extern "C" int tn_version(void) { return TN_VERSION; }
-#ifndef TN_BUILD_ID
-#define TN_BUILD_ID "unknown"
-#endif
-extern "C" const char* tn_build_id(void) { return TN_BUILD_ID; }
+// tn_build_id(): build_id.cpp (its own object, recompiled whenever ANY source of the library changes)
 extern "C" const char* tn_status_string(tn_status s) {
   switch (s) {
     case TN_OK: return "ok";

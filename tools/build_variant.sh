@@ -6,5 +6,7 @@ cd "$(dirname "$0")/../tiny_ntt_amd/csrc"
 mkdir -p ../lib
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c kernels.hip -o ../lib/kernels_$NAME.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libtinyntt_$NAME.so ../lib/kernels_$NAME.o ../lib/capi.o
+[ -f ../lib/capi.o ] || make ../lib/capi.o
+g++ -O2 -fPIC -DTN_BUILD_ID="\"variant-$NAME\"" -c build_id.cpp -o ../lib/build_id_$NAME.o      # never equal to a shipped build's id
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libtinyntt_$NAME.so ../lib/kernels_$NAME.o ../lib/capi.o ../lib/build_id_$NAME.o
 echo built libtinyntt_$NAME.so
