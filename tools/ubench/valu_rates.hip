@@ -90,6 +90,8 @@ K32(xor_inline,   "v_xor_b32 %0, 8, %0")
 K32(sub_co_subb,  "v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %0, vcc, %0, %1, vcc")
 K32(pk_fma_f32_half, "v_fma_f32 %0, %0, %1, %1")
 K32(mad_u32_u24_v3,  "v_mad_u32_u24 %0, %0, %1, %1")
+// every SIMD occupied (32 waves per CU) but nothing for the vector ALU to do: what the package draws with the shader clock up
+K32(snop,            "s_nop 15")
 
 // ---- 64-bit forms
 #define K64(NAME, ASMSTR)                                                        \
@@ -186,6 +188,7 @@ int main(int argc, char** argv) {
     {"v_and_b32 sgpr src", k_and_sgpr, 1}, {"v_and_b32 literal", k_and_literal, 1},
     {"v_lshrrev_b32 sgpr shift", k_lshr_sgpr, 1}, {"v_lshrrev_b32 inline 28", k_lshr_28, 1},
     {"v_sub_u32 sgpr src", k_sub_sgpr, 1}, {"v_mov_b32 sgpr src", k_mov_sgpr, 1}, {"v_xor_b32 inline 8", k_xor_inline, 1},
+    {"s_nop 15 (no ALU work)", k_snop, 1},
     {"ds_write_b64+ds_read_b64", k_lds_rw64, 2},
     {"ds_bpermute_b32+wait", k_bpermute, 1}, {"ds_swizzle_b32+wait", k_swizzle, 1},
   };
