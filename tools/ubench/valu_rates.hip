@@ -152,6 +152,46 @@ __global__ void __launch_bounds__(256) k_lds_rw64(uint32_t* out, uint64_t* cyc, 
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
 }
 
+// v_mad_u64_u32 with BOTH multiplicands changing every instruction (the low and high halves of the neighbouring
+// accumulators, as in a butterfly's multiply-add chain): the multiplier array toggles like it does on real data
+// (in K64(mad_u64_u32) above one multiplicand pair is constant, which reads low)
+__global__ void __launch_bounds__(256) k_mad_u64_varying(uint32_t* out, uint64_t* cyc, uint32_t seed) {
+  uint64_t r[8];
+  for (int i = 0; i < 8; ++i) r[i] = (uint64_t)(seed + threadIdx.x * 8 + i) * 0x9E3779B97F4A7C15ull;
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER; ++it) {
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"((uint32_t)r[(i + 1) & 7]), "v"((uint32_t)(r[(i + 3) & 7] >> 32)) : "vcc");
+  }
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
+// Does the operand ORDER of the multiply matter for power (one port of a multiplier array is usually the recoded one)?
+// varying x constant with the constant (2^29, like SplitK::mulp, or a dense 31-bit one, like a twiddle half) as src0 or src1.
+#define KORD(NAME, CONSTV, ASMSTR)                                                \
+__global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint64_t* cyc, uint32_t seed) { \
+  uint64_t r[8];                                                                 \
+  for (int i = 0; i < 8; ++i) r[i] = (uint64_t)(seed + threadIdx.x * 8 + i) * 0x9E3779B97F4A7C15ull; \
+  uint32_t c = CONSTV;                                                           \
+  asm volatile("" : "+s"(c));                                                    \
+  uint64_t t0 = __builtin_amdgcn_s_memtime();                                    \
+  for (int it = 0; it < ITER; ++it) {                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                \
+      asm volatile(ASMSTR : "+v"(r[i]) : "v"((uint32_t)r[(i + 1) & 7]), "s"(c) : "vcc"); \
+  }                                                                              \
+  uint64_t t1 = __builtin_amdgcn_s_memtime();                                    \
+  uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                         \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));        \
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;\
+}
+KORD(mad_var_x_sparse, 0x20000000u, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+KORD(mad_sparse_x_var, 0x20000000u, "v_mad_u64_u32 %0, vcc, %2, %1, %0")
+KORD(mad_var_x_dense,  0x5A3C96E7u, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+KORD(mad_dense_x_var,  0x5A3C96E7u, "v_mad_u64_u32 %0, vcc, %2, %1, %0")
+
 typedef void (*kern_t)(uint32_t*, uint64_t*, uint32_t);
 struct Entry { const char* name; kern_t k; int instr_per_slot; };
 
@@ -189,6 +229,9 @@ int main(int argc, char** argv) {
     {"v_lshrrev_b32 sgpr shift", k_lshr_sgpr, 1}, {"v_lshrrev_b32 inline 28", k_lshr_28, 1},
     {"v_sub_u32 sgpr src", k_sub_sgpr, 1}, {"v_mov_b32 sgpr src", k_mov_sgpr, 1}, {"v_xor_b32 inline 8", k_xor_inline, 1},
     {"s_nop 15 (no ALU work)", k_snop, 1},
+    {"v_mad_u64_u32 varying", k_mad_u64_varying, 1},
+    {"mad var x 2^29", k_mad_var_x_sparse, 1}, {"mad 2^29 x var", k_mad_sparse_x_var, 1},
+    {"mad var x dense", k_mad_var_x_dense, 1}, {"mad dense x var", k_mad_dense_x_var, 1},
     {"ds_write_b64+ds_read_b64", k_lds_rw64, 2},
     {"ds_bpermute_b32+wait", k_bpermute, 1}, {"ds_swizzle_b32+wait", k_swizzle, 1},
   };
