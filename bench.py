@@ -276,6 +276,7 @@ def main():
     sp = shard_plan(cfg, world, rank, args.rows, args.global_batch)
     rows, first_row = sp["rows"], sp["first_row"]
     bytes_per_product = 3 * cfg["n"] * cfg["elem_bytes"]
+    modmuls = 3 * (cfg["n"] // 2) * (cfg["n"].bit_length() - 1) + 5 * cfg["n"]
     S = "plan"                                               # every launch, sync and HIP event of this run uses the plan's own stream
     sa, sb, stride = seeds_for(first_row)
     a = plan.fill_lcg(rows, sa, stride, stream=S)            # global row r: make_poly(2r+1), make_poly(2r+2)
@@ -396,6 +397,9 @@ def main():
                        "lib_build_id": engine.build_id(),
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "ntts_per_s": round(3 * value, 1),
+            # SURVEY.md §8(d) secondary ceiling: modular multiplications of one product = 3 (n/2) log2 n butterflies + 5 n
+            # (two twists, pointwise, n^-1, untwist), reported beside the HBM roofline (the path is integer-ALU work)
+            "integer_work": {"modmuls_per_product": modmuls, "modmuls_per_s": round(value * modmuls, 1)},
             "control_plane": control_plane,
             "control_plane_ranks": counted,
             "parity": {"first_row_checksum_device": first_sum, "reference_row0_checksum": cfg["checksum_row0"],
