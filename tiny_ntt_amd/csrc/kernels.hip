@@ -50,7 +50,8 @@
                                  //    stride: workgroups do not all run at the same speed, and with a fixed share the slowest sets the time
 #endif
 #ifndef TN_SCHED_CHUNK_BYTES
-#define TN_SCHED_CHUNK_BYTES 65536   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row)
+#define TN_SCHED_CHUNK_BYTES 32768   // dynamic scheduler: bytes of one operand handed out per atomicAdd (>= one row).  The launch's tail is up
+                                     // to one chunk long: 32 / 64 / 128 KiB measured 2.138 / 2.147 / 2.160 ms at n = 4096 / 64-bit
 #endif
 #ifndef TN_SADDR
 #define TN_SADDR 1               // 1: operand rows are addressed as scalar base (+ register offset, scalar unit) + 32-bit thread offset
@@ -79,7 +80,7 @@ namespace tn {
 
 // Row hand-out of the persistent fused kernels.  Dynamic (one atomicAdd on a device counter per chunk of rows) when the
 // launch is long enough for every resident workgroup to take at least four chunks of TN_SCHED_CHUNK_BYTES worth of rows
-// (2 rows at n = 4096 / 64-bit, 16 at n = 1024 / 32-bit): a chunk that large keeps the one counter address from becoming
+// (1 row at n = 4096 / 64-bit, 8 at n = 1024 / 32-bit): a chunk that large keeps the one counter address from becoming
 // the bottleneck (one row per atomic at n = 256 ran 13x slower than a fixed stride; at n = 1024 / 24-bit, batch 16,384, 10x).
 // Otherwise a fixed stride of single rows.
 struct RowPlan { u32 chunk; bool dynamic; };
@@ -349,7 +350,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     constexpr bool SHARE2 = SHARE && TN_SHARE_MID_TW && Cfg::PHASES >= 3 && Cfg::tw_src(PM) == Cfg::TW_LDS &&
                             Cfg::stage_end(PM) - Cfg::stage_begin(PM) == Cfg::LPT;
     const TwRefs<E> twf = {tab_fwd, lds_fwd, prf, nullptr, zero};
-    // A^ stays in registers while b is transformed (no spills at 128 VGPRs since the round-1 trims)
+    // A^ stays in registers while b is transformed
     if constexpr (SHARE2) forward_range<E, Cfg, Pol, 0, PM, KARG>(xa, tau, twf, ar, lds, false, tl);
     else if constexpr (SHARE) forward_range<E, Cfg, Pol, 0, Cfg::PHASES - 1, KARG>(xa, tau, twf, ar, lds, false, tl);
     else forward_all<E, Cfg, Pol>(xa, tau, tab_fwd, lds_fwd, ar, lds, zero);
