@@ -770,15 +770,27 @@ __device__ E* cg_stages(E* src, E* dst, const typename TwOf<E>::type* __restrict
 // bit_reverse_list on load (cg_ntt.py:21-26,:39): reordered[rev(idx)] = f(values[idx]).  Thread t takes idx = t and
 // idx = t + n/2, whose images rev(t) = 2 rev'(t) and 2 rev'(t) + 1 (rev' over log2(n) - 1 bits) are neighbours:
 // coalesced global reads, ONE 16-byte scattered LDS write per pair.  tw == nullptr: plain reduction mod q.
+// lazy (SPLIT policy, lazy stages follow): only congruent mod q and below the lazy stages' input bound (h_cg_lazy_ok):
+// the bare split-constant product of any word, or one fold of it.
+template <typename E, bool SPLIT>
+__device__ __forceinline__ E cg_mul_lazy(E a, const typename TwOf<E>::type* w, const Arith<E>& ar) {
+  if constexpr (SPLIT) return w ? mul_sp(a, *w, ar.sk) : fold(a, ar.k, ar.fold_c);
+  else return cg_mul<E, SPLIT>(a, w, ar);
+}
 template <typename E, int GROUP, int LAYOUT, bool SPLIT>
 __device__ void cg_load_brv(E* buf, const E* __restrict__ in, const typename TwOf<E>::type* __restrict__ tw, u32 n, u32 logn,
-                            const Arith<E>& ar) {
+                            const Arith<E>& ar, bool lazy = false) {
   typedef CgMap<E, GROUP, LAYOUT> M;
   const u32 half = n >> 1;
   for (u32 t = threadIdx.x; t < half; t += blockDim.x) {
     CgPair<E> v;                                                   // twist :82-83 / implicit % of :55-58
+    if (SPLIT && lazy) {
+      v.lo = cg_mul_lazy<E, SPLIT>(in[t], tw ? tw + t : nullptr, ar);
+      v.hi = cg_mul_lazy<E, SPLIT>(in[t + half], tw ? tw + t + half : nullptr, ar);
+    } else {
     v.lo = cg_mul<E, SPLIT>(in[t], tw ? tw + t : nullptr, ar);
     v.hi = cg_mul<E, SPLIT>(in[t + half], tw ? tw + t + half : nullptr, ar);
+    }
     *reinterpret_cast<CgPair<E>*>(buf + M::at(2 * (__brev(t) >> (33 - logn)))) = v;
   }
   __syncthreads();
@@ -826,18 +838,18 @@ cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __re
     const size_t off = (size_t)row * n;
     E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
     if (mode == CG_NTT_FWD || mode == CG_TWIST_FWD) {
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, mode == CG_TWIST_FWD ? pv.psi_pow : nullptr, n, logn, ar);
+      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, mode == CG_TWIST_FWD ? pv.psi_pow : nullptr, n, logn, ar, lazy);
       E* r = stages(p0, p1, pv.omega_pow, tr);
       cg_store_out<E, GROUP, LAYOUT, SPLIT>(out + off, r, n, nullptr, nullptr, ar, lazy);
     } else if (mode == CG_NTT_INV) {                               // cg_intt: cg_ntt.py:68-75
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, nullptr, n, logn, ar);
+      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, nullptr, n, logn, ar, lazy);
       E* r = stages(p0, p1, pv.omega_inv_pow, nullptr);
       cg_store_out<E, GROUP, LAYOUT, SPLIT>(out + off, r, n, nullptr, &ar.fninv, ar);              // :74-75  (fninv: n^-1 in the plan's table format)
     } else {                                                       // nwc_poly_mult: cg_ntt.py:78-92
       // CG_CYCLIC_POLYMUL: the same chain without twist/untwist = python_poly_mult
       // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
       const typename TwOf<E>::type* twist = (mode == CG_CYCLIC_POLYMUL) ? nullptr : pv.psi_pow;
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, twist, n, logn, ar);                      // :82
+      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, twist, n, logn, ar, lazy);                // :82
       E* ra = stages(p0, p1, pv.omega_pow, nullptr);                                              // :86
       // keep A^ in registers: the pairs this thread will need for the pointwise product (t, t + n/2)
       constexpr int KEEP = CgShape<E, GROUP, BIG>::KEEP;                // >= (n/2) / blockDim for every launch shape (launch_cg_t)
@@ -848,21 +860,22 @@ cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __re
         if (t < half) { ka_lo[k] = ra[M::at(t)]; ka_hi[k] = ra[M::at(t + half)]; }
       }
       __syncthreads();
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, b + off, twist, n, logn, ar);                      // :83
+      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, b + off, twist, n, logn, ar, lazy);                // :83
       E* rb = stages(p0, p1, pv.omega_pow, nullptr);                                              // :87
       E* f2 = (rb == p0) ? p1 : p0;
 #pragma unroll
       for (int k = 0; k < KEEP; ++k) {                                                     // :88, stored bit-reversed for :73
         const u32 t = threadIdx.x + (u32)k * blockDim.x;
         if (t < half) {
-          E a0 = ka_lo[k], a1 = ka_hi[k], b0 = rb[M::at(t)], b1 = rb[M::at(t + half)];
-          if (lazy) {                                              // the two-operand Barrett product wants canonical operands
-            a0 = cg_mul<E, SPLIT>(a0, nullptr, ar); a1 = cg_mul<E, SPLIT>(a1, nullptr, ar);
-            b0 = cg_mul<E, SPLIT>(b0, nullptr, ar); b1 = cg_mul<E, SPLIT>(b1, nullptr, ar);
-          }
+          const E a0 = ka_lo[k], a1 = ka_hi[k], b0 = rb[M::at(t)], b1 = rb[M::at(t + half)];
           CgPair<E> v;
-          v.lo = mulmod_barrett(a0, b0, ar.q, ar.mu, ar.k);
-          v.hi = mulmod_barrett(a1, b1, ar.q, ar.mu, ar.k);
+          if (LZ && lazy) {                                        // lazy stages on both sides: the fused kernels' lazy product (< 2q)
+            v.lo = pointwise_lazy(a0, b0, ar);
+            v.hi = pointwise_lazy(a1, b1, ar);
+          } else {
+            v.lo = mulmod_barrett(a0, b0, ar.q, ar.mu, ar.k);
+            v.hi = mulmod_barrett(a1, b1, ar.q, ar.mu, ar.k);
+          }
           *reinterpret_cast<CgPair<E>*>(f2 + M::at(2 * (__brev(t) >> (33 - logn)))) = v;
         }
       }

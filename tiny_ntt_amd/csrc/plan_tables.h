@@ -161,6 +161,8 @@ inline bool h_cg_lazy_ok(int k, u64 c) {
   x.fits(bu - 1 + t); x.fits(B);
   if (bu + t - 1 > B) x.ok = false;
   if (x.folded(B) > (u128)2 * x.q) x.ok = false;    // canonicalisation afterwards: fold, one conditional subtraction
+  if (x.tmax(x.two64) > B) x.ok = false;            // lazy twist on load: the bare product of any word is a valid stage input
+  if (B > (u128)14 * (x.q - 1)) x.ok = false;       // lazy pointwise product (pointwise_lazy): second operand below 14q, result < 2q <= B
   return x.ok;
 }
 
