@@ -172,6 +172,22 @@ def test_benchmark_cli_twin_reports_like_the_reference_binary():
     got = kv(r.stdout)
     assert int(got["forward_ntt_checksum"]) == REF_CHECKSUMS["P4096"][0] and int(got["checksum"]) == REF_CHECKSUMS["P4096"][1]
     assert subprocess.run([exe, "--bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 2
+    # --simple = the other benchmark family (benchmark_simple_60bit.cpp / benchmark_simple.cpp): the O(n^2) direct product timed,
+    # the same five lines; checksum against the reference binary compiled under oracle/_ref
+    for args, refname in ((["--simple", "--reps", "1", "--batch", "8"], "benchmark_simple_60bit_scalar"),
+                          (["--simple", "--reps", "1", "--batch", "8", "--n", "1024", "--q", "8380417", "--psi", "5548360"],
+                           "benchmark_simple_1024_scalar")):
+        out = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.strip().split("\n")
+        assert lines[0] == "benchmark_simple_gpu" and [l.split("=")[0] for l in lines[2:]] == ["total_ns", "avg_ns", "checksum"]
+        simple_ref = os.path.join(ROOT, "oracle", "_ref", refname)
+        if os.path.exists(simple_ref):
+            rl = subprocess.run([simple_ref, "--reps", "1"], stdout=subprocess.PIPE, text=True, timeout=120).stdout.strip().split("\n")
+            assert [l.split("=")[0] for l in rl[2:]] == ["total_ns", "avg_ns", "checksum"]
+            assert kv(out.stdout)["checksum"] == kv("\n".join(rl))["checksum"]
+        else:
+            assert kv(out.stdout)["checksum"] == ("2710933653778106521" if refname.endswith("60bit_scalar") else "15308795525113097448")
 
 
 def test_omega_only_plans_follow_the_reference_for_any_omega(eng):
