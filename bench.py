@@ -40,6 +40,10 @@ import subprocess
 import sys
 import time
 
+# the host driver of this pool supports only dmabuf IPC: without this RCCL / cross-process device memory fails with
+# hipIpcGetMemHandle: invalid argument (already exported on the build and GPU boxes; set here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
