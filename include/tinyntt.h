@@ -155,6 +155,7 @@ tn_status tn_ntt_forward_trace_host(tn_plan *plan, const void *in, void *out, vo
  * forward_ntt_bench(a, out) (benchmark_ntt_60bit.cpp:161-165).
  */
 tn_status tn_twisted_ntt_forward_dev(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant, void *stream);
+tn_status tn_twisted_ntt_forward_host(tn_plan *plan, const void *in, void *out, size_t batch, tn_variant variant);
 
 /*
  * Untwisted (CYCLIC) product: cg_ntt(a), cg_ntt(b), pointwise, cg_intt with omega = psi^2 —
@@ -174,6 +175,7 @@ tn_status tn_pointwise_mul_dev(tn_plan *plan, const void *a, const void *b, void
  * independent on-device checker for the NTT path; not a throughput kernel.
  */
 tn_status tn_schoolbook_dev(tn_plan *plan, const void *a, const void *b, void *c, size_t batch, void *stream);
+tn_status tn_schoolbook_host(tn_plan *plan, const void *a, const void *b, void *c, size_t batch);
 
 /*
  * Copy one of the plan's constant tables to the host as uint64_t values (the constants only,

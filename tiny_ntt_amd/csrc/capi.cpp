@@ -478,6 +478,19 @@ extern "C" tn_status tn_ntt_forward_host(tn_plan* p, const void* in, void* out, 
 extern "C" tn_status tn_ntt_inverse_host(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v) {
   return ntt_host(p, CG_NTT_INV, in, out, nullptr, batch, v, "tn_ntt_inverse_host");
 }
+extern "C" tn_status tn_twisted_ntt_forward_host(tn_plan* p, const void* in, void* out, size_t batch, tn_variant v) {
+  return ntt_host(p, CG_TWIST_FWD, in, out, nullptr, batch, v, "tn_twisted_ntt_forward_host");
+}
+extern "C" tn_status tn_schoolbook_host(tn_plan* p, const void* a, const void* b, void* c, size_t batch) {
+  tn_status st = check_ptrs(p, a, b, c, batch, "tn_schoolbook_host");
+  if (st || batch == 0) return st;
+  std::lock_guard<std::mutex> host_lock(p->host_mu);
+  TN_ON_DEVICE(p);
+  const void* in[2] = {a, b};
+  return host_pipeline(p, 2, in, c, batch, [&](const void* da, const void* db, void* dc, size_t rows) {
+    return tn_schoolbook_dev(p, da, db, dc, rows, nullptr);
+  });
+}
 extern "C" tn_status tn_ntt_forward_trace_host(tn_plan* p, const void* in, void* out, void* trace, tn_variant v) {
   if (!trace) return fail(TN_EINVAL, "tn_ntt_forward_trace_host: trace is NULL");
   return ntt_host(p, CG_NTT_FWD, in, out, trace, 1, v, "tn_ntt_forward_trace_host");

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "tn_poly_mult_dev", "tn_poly_mult_host", "tn_plan_set_host_chunk_rows", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
     "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
     "tn_ntt_forward_host", "tn_ntt_inverse_host", "tn_ntt_forward_trace_host", "tn_twisted_ntt_forward_dev",
+    "tn_twisted_ntt_forward_host", "tn_schoolbook_host",
     "tn_fill_lcg_dev", "tn_checksum_rows_dev", "tn_plan_synchronize", "tn_time_poly_mult_dev",
     "tn_kernel_name", "tn_last_error", "tn_status_string", "tn_version", "tn_build_id",
 )
@@ -88,7 +89,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.tn_plan_export_table.argtypes = [vp, ci, vp]
     for name in ("tn_ntt_forward_dev", "tn_ntt_inverse_dev", "tn_twisted_ntt_forward_dev"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz, ci, vp]
-    for name in ("tn_ntt_forward_host", "tn_ntt_inverse_host"):
+    lib.tn_schoolbook_host.argtypes = [vp, vp, vp, vp, sz]
+    for name in ("tn_ntt_forward_host", "tn_ntt_inverse_host", "tn_twisted_ntt_forward_host"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz, ci]
     lib.tn_ntt_forward_trace_host.argtypes = [vp, vp, vp, vp, ci]
     lib.tn_fill_lcg_dev.argtypes = [vp, vp, sz, u64, u64, vp]
