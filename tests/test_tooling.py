@@ -55,3 +55,32 @@ def test_barrett_and_montgomery_constants():
             a, b = rnd.randrange(q), rnd.randrange(q)
             assert numtheory.barrett_reduce(a * b, q) == a * b % q
         assert numtheory.barrett_reduce((q - 1) * (q - 1), q) == 1
+
+
+def test_command_line_tool_writes_the_reference_files(tmp_path, capsys):
+    """python -m tiny_ntt_amd.twiddles forward|inverse|find-psi|constants: the reference's scripts/ as one tool; the hex files it
+    writes hash to the reference's own rtl/twiddle_*.hex (digests committed as a fixture)."""
+    with open(os.path.join(GOLDEN, "reference_hex_digests.json")) as f:
+        digests = json.load(f)
+    checked = 0
+    for name, d in digests.items():
+        upper = d["first"][1] == d["first"][1].upper() and d["first"][1] != d["first"][1].lower()
+        if not upper:
+            continue                              # the tool writes uppercase like the scripts; two of the reference's files are lowercase
+        n, q, psi = PARAMS[d["tag"]]
+        kind = "forward" if d["kind"] == "fwd" else "inverse"
+        width = len(d["first"][0]) * 4
+        assert twiddles.main([kind, "--n", str(n), "--q", str(q), "--psi", str(psi), "--width", str(width), "--output-dir", str(tmp_path)]) == 0
+        text = open(tmp_path / f"twiddle_{kind}.hex").read()
+        assert hashlib.sha256(text.encode()).hexdigest() == d["sha256"], name
+        checked += 1
+    assert checked >= 4
+    assert twiddles.main(["forward", "--psi", "5", "--output-dir", str(tmp_path)]) == 1        # not a 2N-th root: refused like the script's assert
+    capsys.readouterr()
+    assert twiddles.main(["find-psi", "4096", "8380417"]) == 0
+    assert "parameter PSI = 687;" in capsys.readouterr().out                                   # scripts/find_psi.py's answer (fixture reference_find_psi.json)
+    assert twiddles.main(["find-psi", "4096", "1152921504606830593"]) == 1                     # none below 10^4, like the script
+    capsys.readouterr()
+    assert twiddles.main(["constants", "--q", "8380417"]) == 0
+    out = capsys.readouterr().out
+    assert "K = 23" in out and "MU = floor(2^46 / Q) = 8396807" in out                          # rtl/barrett_reduction.v:6-7

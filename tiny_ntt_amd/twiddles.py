@@ -81,3 +81,71 @@ def plan_from_hex(forward_hex_path: str, q: int, device: int = 0):
     from . import engine
     table = read_hex(forward_hex_path)
     return engine.get_plan(len(table), q, psi_from_table(table, q), device)
+
+
+# ---- command line: the reference's scripts/ as one tool --------------------------------------
+#   python -m tiny_ntt_amd.twiddles forward  [--n N --q Q --psi PSI --width BITS --output-dir DIR]   scripts/generate_twiddles.py:136-200
+#   python -m tiny_ntt_amd.twiddles inverse  [...same...]                                             scripts/generate_inverse_twiddles.py:158-
+#   python -m tiny_ntt_amd.twiddles find-psi [N Q]                                                    scripts/find_psi.py:64-85
+#   python -m tiny_ntt_amd.twiddles constants [--q Q]                                                 scripts/precompute_constants.py:113-
+# Defaults are the reference's (N = 256, Q = 8380417, psi = 1239911, 24-bit words; find-psi: N = 4096).  The hex files carry
+# the reference's names (twiddle_forward.hex / twiddle_inverse.hex) and its $readmemh format: ceil(width / 4) uppercase digits.
+def _write_table(kind: str, args) -> int:
+    n, q, psi = args.n, args.q, args.psi
+    if pow(psi, 2 * n, q) != 1 or pow(psi, n, q) != q - 1:               # verify_psi_properties (generate_twiddles.py:44-56)
+        print(f"psi={psi} is not a primitive {2 * n}-th root of unity mod {q}")
+        return 1
+    table = forward_table(n, q, psi) if kind == "forward" else inverse_table(n, q, psi)
+    digits = (args.width + 3) // 4
+    if q.bit_length() > args.width:
+        print(f"--width {args.width} is narrower than the modulus ({q.bit_length()} bits)")
+        return 1
+    import os
+    os.makedirs(args.output_dir, exist_ok=True)
+    path = os.path.join(args.output_dir, f"twiddle_{kind}.hex")
+    with open(path, "w") as f:
+        f.write("".join(f"{v:0{digits}X}\n" for v in table))
+    print(f"Parameters: N={n}, Q={q}, psi={psi}")
+    print(f"  First 5: {table[:5]}")
+    print(f"  Last 5:  {table[-5:]}")
+    print(f"Generated hex file: {path}")
+    print(f"  Entries: {len(table)}")
+    print(f"  Width: {args.width} bits ({digits} hex digits)")
+    return 0
+
+
+def main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m tiny_ntt_amd.twiddles", description=__doc__.splitlines()[0])
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for kind in ("forward", "inverse"):
+        g = sub.add_parser(kind, help=f"write twiddle_{kind}.hex")
+        g.add_argument("--n", type=int, default=256)
+        g.add_argument("--q", type=int, default=8380417)
+        g.add_argument("--psi", type=int, default=1239911)
+        g.add_argument("--width", type=int, default=24)
+        g.add_argument("--output-dir", default=".")
+    f = sub.add_parser("find-psi", help="smallest psi in [2, 10000) with psi^N = -1 (mod Q)")
+    f.add_argument("n", type=int, nargs="?", default=4096)
+    f.add_argument("q", type=int, nargs="?", default=8380417)
+    c = sub.add_parser("constants", help="Barrett / Montgomery constants of a modulus")
+    c.add_argument("--q", type=int, default=8380417)
+    args = ap.parse_args(argv)
+    if args.cmd in ("forward", "inverse"):
+        return _write_table(args.cmd, args)
+    if args.cmd == "find-psi":
+        psi = numtheory.find_psi(args.n, args.q, log_fn=print)
+        if psi is None:
+            return 1
+        print(f"parameter PSI = {psi};")
+        return 0
+    k, mu = numtheory.barrett_constants(args.q)
+    mk, R, r_inv, q_prime = numtheory.montgomery_constants(args.q)
+    print(f"Q = {args.q}")
+    print(f"Barrett:    K = {k}  MU = floor(2^{2 * k} / Q) = {mu}")
+    print(f"Montgomery: K = {mk}  R = 2^{mk} = {R}  R_INV = {r_inv}  Q_PRIME = {q_prime}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
