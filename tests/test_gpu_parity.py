@@ -510,3 +510,14 @@ def test_n8192_60bit_matches_reference_golden_and_oracle(eng, oracle):
     X = plan.ntt_forward(A[:40])
     assert np.array_equal(X, plan.ntt_forward(A[:40], variant="cg")) and np.array_equal(plan.ntt_inverse(X), A[:40] % np.uint64(q))
     assert np.array_equal(plan.cyclic_poly_mult(A[:40], Bm[:40]), plan.cyclic_poly_mult(A[:40], Bm[:40], variant="cg"))
+
+
+@pytest.mark.gpu
+def test_wide_parity_fuzz_all_sizes_and_word_lengths():
+    """tests/dev/gpu_fuzz.py: n in {8 ... 8192} x NTT primes of every bit length 14..62 x fused + three random constant-geometry
+    variants, special rows (q-1, unreduced words, zeros, a monomial) and random ones, against the CPU oracle (~2,600 checks, seconds)."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "gpu_fuzz.py"), "11", "200"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and ", 0 mismatches" in r.stdout, r.stdout[-2000:]
