@@ -191,6 +191,7 @@ class Emu:
         L.emu_fused_poly_mult.argtypes = [u32, u64, u64, ci, P64, P64, P64, sz]
         L.emu_is_lazy.argtypes = [u32, u64, u64]
         L.emu_cg.argtypes = [u32, u64, u64, ci, P64, P64, P64, P64]
+        L.emu_cgm.argtypes = [u32, u64, u64, ci, ci, ci, ci, ci, P64, P64, P64, P64]
         L.emu_fused_ntt.argtypes = [u32, u64, u64, ci, ci, P64, P64]
         L.emu_mul_tw64.argtypes = [u64, u64, u64]; L.emu_mul_tw64.restype = u64
         L.emu_mul_tw64_lazy.argtypes = [u64, u64, u64]; L.emu_mul_tw64_lazy.restype = u64
@@ -228,6 +229,20 @@ class Emu:
         tr = np.empty((n.bit_length() - 1, n), dtype=np.uint64) if trace else None
         rc = self.lib.emu_cg(n, q, psi, mode, p64(a), p64(b) if b is not None else None, p64(out), p64(tr) if trace else None)
         assert rc == 0
+        return (out, tr) if trace else out
+
+    def cgm(self, n, q, psi, mode, a, b=None, group=8, layout=0, am=0, flags=0, trace=False):
+        """The multi-stage trips of cg_kernels.hip stepped on the CPU.  Returns None when the combination is unsupported
+        (log2 n < log2(2 group); split arithmetic on a plan that is not lazy with 64-bit lanes)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+        out = np.empty_like(a)
+        tr = np.empty((n.bit_length() - 1, n), dtype=np.uint64) if trace else None
+        rc = self.lib.emu_cgm(n, q, psi, mode, group, layout, am, flags, p64(a), p64(b) if b is not None else None, p64(out),
+                              p64(tr) if trace else None)
+        if rc == 7:
+            return None
+        assert rc == 0, rc
         return (out, tr) if trace else out
 
 

@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <vector>
 #include "../../tiny_ntt_amd/csrc/plan_tables.h"
+#include "../../tiny_ntt_amd/csrc/cg_core.h"
 
 using namespace tn;
 
@@ -206,6 +207,116 @@ int cg_emu(const HostTables& t, int mode, const u64* a, const u64* b, u64* out, 
   return 0;
 }
 
+
+// The constant-geometry kernels' trips (cg_core.h / cg_kernels.hip), one emulated lane-step at a time with the LDS image and
+// the LDS twiddle table between them.  mode: 0 cg_ntt, 1 cg_intt, 2 nwc_poly_mult, 3 twist + cg_ntt, 4 cyclic product.
+// flags: bit 0 = wave-uniform trips take their twiddles from the global table (scalar loads in the kernel) instead of LDS;
+//        bit 1 = no reversal: the inverse transform of a product reads a re-staged inverse table (plans whose omega is not a root)
+template <typename E, int GROUP, int LAYOUT, int AM>
+int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b, u64* out, u64* trace) {
+  typedef CgGeom<GROUP> Ge;
+  typedef CgMap<E, GROUP, LAYOUT> M;
+  typedef CgArith<E, AM> A;
+  typedef typename TwOf<E>::type Tw;
+  constexpr int R = Ge::R, L = Ge::L;
+  const u32 n = t.n, logn = t.logn;
+  if ((int)logn < L) return 7;
+  if (trace && AM == CGA_SPLIT_LAZY) return 7;
+  const Arith<E> ar = h_make_arith<E>(t);
+  const u32 TP = n >> L, ntrips = Ge::ntrips(logn), r1 = Ge::first_stages(logn);
+  const bool split = AM != CGA_SHOUP;
+  auto table = [&](const std::vector<u64>& v) { return split ? h_fused_table<E>(v, t) : h_tw_table<E>(v, t.q); };
+  const std::vector<Tw> fwd = table(t.omega_pow), inv = table(t.omega_inv_pow), psi_pow = table(t.psi_pow), psi_inv_ninv = table(t.psi_inv_ninv);
+  const Tw ninv = split ? ar.fninv : ar.ninv;
+  const bool big = TP >= 256;
+  std::vector<E> img(M::span(n) + 4, (E)0xDEADBEEFu);
+  std::vector<Tw> ldstab(n / 2 + 1);
+  auto stage_table = [&](const std::vector<Tw>& g) { for (u32 j = 0; j <= n / 2; ++j) ldstab[cg_twmap<LAYOUT>(j, big)] = g[j]; };
+  struct Regs { E x[R]; };
+
+  // x: registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list) -> natural order (x[e] = output ls + e TP)
+  auto transform = [&](std::vector<Regs>& x, bool inverse, bool rev, u64* tr) {
+    const Tw* glob = inverse ? inv.data() : fwd.data();
+    auto run_first = [&](auto nst_) {
+      constexpr int NST = decltype(nst_)::value;
+      for (u32 ls = 0; ls < TP; ++ls) {
+        const u32 T = h_brv(ls, logn - L);
+        cg_trip<E, GROUP, AM, NST, false>(x[ls].x, ar,
+          [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1))]; },
+          [&](auto j_) { if (tr) for (u32 e = 0; e < (u32)R; ++e) tr[(size_t)decltype(j_)::value * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[ls].x[e]; });
+        if (ntrips > 1) for (u32 e = 0; e < (u32)R; ++e) img[M::at(Ge::pos(logn, NST, T, e))] = x[ls].x[e];
+      }
+    };
+    switch (r1) { case 1: run_first(std::integral_constant<int, 1>()); break;
+                  case 2: if constexpr (L >= 2) run_first(std::integral_constant<int, 2>()); break;
+                  case 3: if constexpr (L >= 3) run_first(std::integral_constant<int, 3>()); break;
+                  case 4: if constexpr (L >= 4) run_first(std::integral_constant<int, 4>()); break; }
+    u32 s0 = r1;
+    for (u32 trip = 1; trip < ntrips; ++trip, s0 += L) {
+      for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; e += 2) {
+        const CgPair<E> v = *reinterpret_cast<const CgPair<E>*>(&img[M::step(M::at(R * ls), e)]);
+        x[ls].x[e] = v.lo; x[ls].x[e + 1] = v.hi;
+      }
+      for (auto& v : img) v = (E)0xDEADBEEFu;
+      const bool uniform = (flags & 1) && (int)logn - (int)s0 - L >= 6;     // the trip's twiddles depend on T >> 6 only
+      for (u32 ls = 0; ls < TP; ++ls) {
+        const u32 T = ls, base0 = cg_tw_base0<GROUP>(logn, s0, T);
+        auto after = [&](auto j_) { if (tr) for (u32 e = 0; e < (u32)R; ++e) tr[(size_t)(s0 + decltype(j_)::value) * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[ls].x[e]; };
+        auto idx = [&](int j, u32 h) { return h * (n >> (j + 1)) + (base0 >> j); };
+        if (uniform) cg_trip<E, GROUP, AM, L, false>(x[ls].x, ar, [&](auto j_, auto h_) { return glob[idx(decltype(j_)::value, decltype(h_)::value)]; }, after);
+        else if (rev) cg_trip<E, GROUP, AM, L, true>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<LAYOUT>(n / 2 - idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
+        else cg_trip<E, GROUP, AM, L, false>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<LAYOUT>(idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
+      }
+      if (trip + 1 < ntrips) for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) img[M::at(Ge::pos(logn, L, ls, e))] = x[ls].x[e];
+    }
+  };
+  auto load = [&](std::vector<Regs>& x, const u64* in, const Tw* twist) {
+    for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) {
+      const u32 i = ls + e * TP;
+      x[ls].x[Ge::brvL(e)] = twist ? A::in_mul((E)in[i], twist[i], ar) : A::in_red((E)in[i], ar);
+    }
+  };
+  std::vector<Regs> xa(TP), xb(TP);
+  if (mode == 0 || mode == 3) {
+    stage_table(fwd);
+    load(xa, a, mode == 3 ? psi_pow.data() : nullptr);
+    transform(xa, false, false, trace);
+    for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) out[ls + e * TP] = A::out_canon(xa[ls].x[e], ar);
+  } else if (mode == 1) {
+    stage_table(inv);
+    load(xa, a, nullptr);
+    transform(xa, true, false, nullptr);
+    for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) out[ls + e * TP] = A::out_mul(xa[ls].x[e], ninv, ar);
+  } else {
+    const Tw* twist = mode == 4 ? nullptr : psi_pow.data();
+    const bool rev = !(flags & 2);
+    stage_table(fwd);
+    load(xa, a, twist); transform(xa, false, false, nullptr);
+    load(xb, b, twist); transform(xb, false, false, nullptr);
+    for (u32 ls = 0; ls < TP; ++ls) {
+      E c[R];
+      for (u32 e = 0; e < (u32)R; ++e) c[e] = A::pointwise(xa[ls].x[e], xb[ls].x[e], ar);
+      for (u32 e = 0; e < (u32)R; ++e) xa[ls].x[Ge::brvL(e)] = c[e];
+    }
+    if (!rev) stage_table(inv);
+    transform(xa, true, rev, nullptr);
+    for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) {
+      const u32 i = ls + e * TP;
+      out[i] = A::out_mul(xa[ls].x[e], twist ? psi_inv_ninv[i] : ninv, ar);
+    }
+  }
+  return 0;
+}
+
+template <typename E, int AM>
+int cgm_dispatch(const HostTables& t, int mode, int group, int layout, int flags, const u64* a, const u64* b, u64* out, u64* trace) {
+#define TN_CGM(G, LY) if (group == G && layout == LY) return cgm_emu<E, G, LY, AM>(t, mode, flags, a, b, out, trace);
+  TN_CGM(1, 0) TN_CGM(1, 1) TN_CGM(1, 2) TN_CGM(2, 0) TN_CGM(2, 1) TN_CGM(2, 2)
+  TN_CGM(4, 0) TN_CGM(4, 1) TN_CGM(4, 2) TN_CGM(8, 0) TN_CGM(8, 1) TN_CGM(8, 2)
+#undef TN_CGM
+  return 7;
+}
+
 // Layout probes for the LDS bank-conflict simulator (tests/test_lds_banks.py).
 // what: 0 THREADS, 1 R, 2 PHASES, 3 lds_elems, 4 ex_wave_local(arg0), 5 jidx(arg0=phase, arg1=tau, arg2=r),
 //       6 ex_addr(arg0=exchange, arg1=j), 7 pos(arg0)
@@ -261,6 +372,21 @@ int emu_cg(uint32_t n, uint64_t q, uint64_t psi, int mode, const uint64_t* a, co
   if (!params_ok(n, q, psi)) return 2;
   const HostTables t = h_build_tables(n, q, psi, true);
   return t.elem_bytes == 8 ? cg_emu<u64>(t, mode, a, b, out, trace) : cg_emu<u32>(t, mode, a, b, out, trace);
+}
+
+// The trips of cg_kernels.hip stepped on the CPU.  am: 0 Shoup records, 1 split records canonical, 2 split records lazy
+// (1 and 2 need a plan that is lazy with 64-bit lanes).  7 = unsupported combination.
+int emu_cgm(uint32_t n, uint64_t q, uint64_t psi, int mode, int group, int layout, int am, int flags, const uint64_t* a,
+            const uint64_t* b, uint64_t* out, uint64_t* trace) {
+  if (!params_ok(n, q, psi)) return 2;
+  const HostTables t = h_build_tables(n, q, psi, true);
+  if (am != 0 && !(t.lazy && t.elem_bytes == 8 && (am == 1 || t.cg_lazy))) return 7;
+  if (t.elem_bytes == 8) {
+    if (am == 0) return cgm_dispatch<u64, CGA_SHOUP>(t, mode, group, layout, flags, a, b, out, trace);
+    if (am == 1) return cgm_dispatch<u64, CGA_SPLIT_CANON>(t, mode, group, layout, flags, a, b, out, trace);
+    return cgm_dispatch<u64, CGA_SPLIT_LAZY>(t, mode, group, layout, flags, a, b, out, trace);
+  }
+  return cgm_dispatch<u32, CGA_SHOUP>(t, mode, group, layout, flags, a, b, out, trace);
 }
 
 // see cfg_probe() above for `what`

@@ -72,6 +72,58 @@ def test_cg_emulation_matches_golden(emu, golden, tag):
         assert np.array_equal(emu.cg(g.n, g.q, g.psi, 3, g["lcg12_mul_a"]), g["lcg1_fwd"])
 
 
+@pytest.mark.parametrize("tag", ["P4", "P256", "P1024", "P4096", "P4096_60"])
+def test_cg_trips_emulation_matches_golden_and_oracle(emu, oracle, golden, tag):
+    """The constant-geometry kernels' multi-stage trips (cg_core.h: log2(2 GROUP) stages per LDS round trip, first trip fed
+    straight from the bit-reversed load, one LDS twiddle table read backwards for the inverse) stepped lane-step by
+    lane-step: every lane grouping x LDS layout x arithmetic x twiddle source, products, transforms and per-stage traces."""
+    g = golden(tag)
+    n, q, psi = g.n, g.q, g.psi
+    rng = np.random.default_rng(3)
+    word = 2 ** 32 - 1 if q < 2 ** 31 else 2 ** 64 - 1
+    a = rng.integers(0, word, n, dtype=np.uint64, endpoint=True); b = np.full(n, word, dtype=np.uint64)       # any word is taken mod q
+    ref = oracle.poly_mult(a[None], b[None], q, psi)[0]
+    full_trace = {name: emu.cg(n, q, psi, 0, g[name + "_x"], trace=True)[1] for name in g.cases("ntt")}
+    ran = 0
+    for group in (1, 2, 4, 8):
+        for layout in (0, 1, 2):
+            for am in (0, 1, 2):
+                if emu.cgm(n, q, psi, 0, a, group=group, layout=layout, am=am) is None:
+                    continue                                  # log2 n < log2(2 group), or split arithmetic on a Shoup plan
+                ran += 1
+                for flags in (0, 1, 2, 3):
+                    assert np.array_equal(emu.cgm(n, q, psi, 2, a, b, group=group, layout=layout, am=am, flags=flags), ref), (group, layout, am, flags)
+                for name in g.cases("poly_mult"):
+                    assert np.array_equal(emu.cgm(n, q, psi, 2, g[name + "_a"], g[name + "_b"], group=group, layout=layout, am=am), g[name + "_c"]), name
+                for name in g.cases("ntt"):
+                    if am != 2:                               # traces need canonical stages
+                        out, tr = emu.cgm(n, q, psi, 0, g[name + "_x"], group=group, layout=layout, am=am, flags=1, trace=True)
+                        assert np.array_equal(out, g[name + "_X"]) and np.array_equal(tr, full_trace[name]), (name, group, layout, am)
+                        assert np.array_equal(tr[:, :min(16, n)], g[name + "_trace16"]), name
+                    assert np.array_equal(emu.cgm(n, q, psi, 0, g[name + "_x"], group=group, layout=layout, am=am), g[name + "_X"]), name
+                    assert np.array_equal(emu.cgm(n, q, psi, 1, g[name + "_X"], group=group, layout=layout, am=am), g[name + "_x"] % np.uint64(q)), name
+                if tag != "P4":
+                    assert np.array_equal(emu.cgm(n, q, psi, 3, g["lcg12_mul_a"], group=group, layout=layout, am=am), g["lcg1_fwd"])
+    assert ran >= (6 if tag == "P4" else 12)
+
+
+def test_cg_trips_emulation_every_size(emu, oracle):
+    """n = 4 ... 8192 (partial first trips of every length, single-trip transforms) x word sizes."""
+    from conftest import ntt_prime_below
+    for logn in range(2, 14):
+        n = 1 << logn
+        for limit in (2 ** 23, 2 ** 31 - 1, 2 ** 45, 2 ** 60):
+            q = ntt_prime_below(limit, n)
+            psi = next(p for p in (pow(x, (q - 1) // (2 * n), q) for x in range(2, 500)) if pow(p, n, q) == q - 1)
+            rng = np.random.default_rng(logn)
+            a = rng.integers(0, q, n, dtype=np.uint64); b = rng.integers(0, q, n, dtype=np.uint64)
+            ref = oracle.poly_mult(a[None], b[None], q, psi)[0]
+            for group in (1, 2, 4, 8):
+                for am in (0, 1, 2):
+                    c = emu.cgm(n, q, psi, 2, a, b, group=group, layout=2 if group & 5 else 1, am=am, flags=1)
+                    assert c is None or np.array_equal(c, ref), (n, q, group, am)
+
+
 EDGE64 = [0, 1, 2, 2 ** 32 - 1, 2 ** 32, 2 ** 60 - 1, 2 ** 60, 2 ** 63, 2 ** 64 - 1]
 
 

@@ -400,7 +400,7 @@ def test_concurrent_launches_of_one_plan_on_several_streams(eng):
             assert torch.equal(outs[i], ref[i]) and torch.equal(outs_t[i], ref_t[i]), (rep, i)
     # and many back-to-back launches on one stream (the counter pairs re-arm themselves and wrap around the ring)
     a, b = ins[5]
-    for _ in range(4300):                      # more launches than the ring has slots (tn_plan::SCHED_SLOTS = 4096)
+    for _ in range(1100):                      # more launches than the ring has slots (tn_plan::SCHED_SLOTS = 1024)
         c = plan.poly_mult(a, b)
     torch.cuda.synchronize()
     assert torch.equal(c, ref[5])

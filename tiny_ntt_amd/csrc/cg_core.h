@@ -1,0 +1,168 @@
+// cg_core.h — the per-lane-step body of the constant-geometry kernels (cg_kernels.hip), written as host+device templates
+// so that tests/emu can step the very same index math and arithmetic on the CPU.  Nothing here touches the oracle.
+//
+// What it computes: the reference's constant-geometry transform (new_reference/cg_ntt.py:49-64) —
+//   stage s = 1 .. log2 n, k = n >> s, butterfly i in [0, n/2):  w = omega^(k (i // k)),
+//   A[i] = a[2i] + w a[2i+1],  A[i + n/2] = a[2i] - w a[2i+1]
+// — with GROUP consecutive butterflies per lane-step (8 = cg_ntt_8butterfly.py:61-89).
+//
+// How (round 3): the G sums a lane-step writes to A[i0 .. i0+G) are exactly the inputs of butterflies i0/2 .. i0/2+G/2-1
+// of the NEXT stage and its G differences those of butterflies i0/2+n/4 ..; so a lane-step that holds R = 2G
+// neighbouring coefficients runs L = log2(R) stages in registers ("a trip") before anything has to move: per stage the
+// registers go through the same perfect shuffle the list does (z[g] = sum_g, z[G+g] = dif_g), and after j stages
+// register e holds position
+//     pos(j, T, e) = (R T >> j) + (e mod 2^(L-j)) + (e >> (L-j)) (n >> j)          (T = the lane-step's index)
+// of that stage's list.  After a full trip that is T + e n/R: a stride-n/R column, which one LDS transpose (write
+// columns, read R neighbours) turns into the next trip's input.  log2 n stages = ceil(log2 n / L) trips; the FIRST
+// trip takes the remainder so that the last one is full and its output columns T + e n/R are unit-stride across lanes
+// in global memory.  For the same reason the bit-reversed load (cg_ntt.py:39) costs no transpose either: lane-step t
+// loads column t + e' n/R, which is the R-neighbourhood of index brv(t) of the bit-reversed list, and first-trip
+// twiddles do not depend on the lane-step (omega^(k (i // k)) with i < k), so thread t simply plays lane-step brv(t).
+// The product keeps A^ and B^ in those columns, multiplies them in registers, and the inverse transform starts from
+// them the same way: no LDS round trip between the forward and the inverse transforms.
+#pragma once
+#include "fused_core.h"
+
+namespace tn {
+
+enum CgLayout { CG_LINEAR = 0, CG_PADDED = 1, CG_SWIZZLED = 2 };
+// Arithmetic of the butterflies: Shoup records + compare-select (any modulus); the plan's split-constant records with
+// canonical values at every step (per-stage traces of a lazy 64-bit plan); split-constant records, values only congruent
+// mod q between stages (h_cg_lazy_ok replays the bounds for the plan's (k, c)).
+enum CgArithMode { CGA_SHOUP = 0, CGA_SPLIT_CANON = 1, CGA_SPLIT_LAZY = 2 };
+
+template <int V> struct ILog2 { static constexpr int value = 1 + ILog2<V / 2>::value; };
+template <> struct ILog2<1> { static constexpr int value = 0; };
+
+template <int GROUP> struct CgGeom {
+  static constexpr int G = GROUP, R = 2 * GROUP, L = ILog2<R>::value;
+  static constexpr u32 brvL(u32 e) {
+    u32 r = 0;
+    for (int i = 0; i < L; ++i) r |= ((e >> i) & 1u) << (L - 1 - i);
+    return r;
+  }
+  TN_HD static u32 ntrips(u32 logn) { return (logn + L - 1) / L; }
+  TN_HD static u32 first_stages(u32 logn) { return logn - (ntrips(logn) - 1) * L; }
+  // position (in the list of that stage) held by register e after j stages of a trip run as lane-step T
+  TN_HD static u32 pos(u32 logn, int j, u32 T, u32 e) {
+    return (((u32)R * T) >> j) + (e & (((u32)R >> j) - 1u)) + ((e >> (L - j)) << (logn - j));
+  }
+};
+
+// LDS image of one polynomial.  LAYOUT:
+//   CG_LINEAR   element x at x.
+//   CG_PADDED   16 bytes of padding after every R = 2 GROUP elements (one lane-step's contiguous read).
+//   CG_SWIZZLED x ^ (((x >> 4) & 15) << 1) ^ (((x >> 9) & 7) << 1): pairs (2i, 2i+1) stay adjacent and 16-byte aligned
+//               (bit 0 untouched); chosen by search over the gfx950 banking model (tools/cg_layout_search.py,
+//               tests/test_lds_banks.py) for the accesses of the trips: 128-bit reads of a lane-step's R neighbours,
+//               element-wide column writes T + e n/R for T = lane (later trips) and T = brv(lane) (first trip).
+template <typename E, int GROUP, int LAYOUT> struct CgMap {
+  static constexpr u32 CH = 2 * GROUP, PADE = 16 / sizeof(E);
+  TN_HD static u32 at(u32 x) {
+    if (LAYOUT == CG_PADDED) return x + (x / CH) * PADE;
+    if (LAYOUT == CG_SWIZZLED) return x ^ (((x >> 4) & 15u) << 1) ^ (((x >> 9) & 7u) << 1);
+    return x;
+  }
+  TN_HD static constexpr u32 span(u32 n) { return LAYOUT == CG_PADDED ? n + (n / CH) * PADE : n; }
+  // at(x + d) from at(x) for x a multiple of R, d < R <= 16: the swizzle only XORs bits 1..4 with functions of bits >= 4
+  TN_HD static u32 step(u32 ax, u32 d) { return LAYOUT == CG_SWIZZLED ? (ax ^ d) : (ax + d); }
+};
+// The twiddle table omega^j, j <= n/2, staged in LDS: record j at twmap(j).  Swizzled with the image: the last trip reads it
+// at strides G, G/2, .., 1 records across lanes, and 16-byte records at a power-of-two stride hit the same banks.
+template <int LAYOUT> TN_HD u32 cg_twmap(u32 j, bool big) { return (LAYOUT == CG_SWIZZLED && big) ? (j ^ ((j >> 4) & 15u)) : j; }
+
+// two neighbouring coefficients (2i, 2i+1): one 16-byte (8-byte for 32-bit lanes) LDS access in every layout
+template <typename E> struct alignas(2 * sizeof(E)) CgPair { E lo, hi; };
+
+template <typename E, int AM> struct CgArith {
+  typedef typename TwOf<E>::type Tw;
+  static constexpr bool SPLIT = AM != CGA_SHOUP, LAZY = AM == CGA_SPLIT_LAZY;
+  typedef Policy<E, SPLIT> P;
+  // a * w for ANY word a (twist, cg_ntt.py:82-83) / a mod q (the implicit % of :55-58).  Canonical, or (lazy) only congruent and
+  // below the lazy butterflies' input bound: the bare split-constant product, or one fold.
+  TN_HD static E in_mul(E a, Tw w, const Arith<E>& ar) {
+    if constexpr (LAZY) return mul_sp(a, w, ar.sk);
+    else if constexpr (SPLIT) return P::mul_tw_canon(a, w, ar);
+    else return mul_tw(a, w, ar.q);
+  }
+  TN_HD static E in_red(E a, const Arith<E>& ar) {
+    if constexpr (LAZY) return fold(a, ar.k, ar.fold_c);
+    else if constexpr (SPLIT) return P::canon(a, ar);
+    else return mul_tw(a, ar.one, ar.q);
+  }
+  // The reference butterfly (cg_ntt.py:57-59): t = omega * right, (left + t) % q, (left - t) % q.
+  //   Shoup: product and compare-select (any modulus).
+  //   split, canonical: the product rides the multiply-add chain as left + t' with t' < 5q, the difference is
+  //     left + 5q - t'; one fold (-> below 2q) and one conditional subtraction make each canonical.
+  //   split, lazy: left is folded (< 2^k + eps), the difference is 2 left + 6q - x.  With every input below 7.01 * 2^k (true
+  //     for canonical inputs and preserved: t' < 4 * 2^k + 7.01 * 2^k / 8 + eps < 4.9 * 2^k <= 6q) both outputs stay below
+  //     7.01 * 2^k; h_cg_lazy_ok() replays these bounds exactly for the plan's (k, c).
+  TN_HD static void bf(E left, E right, Tw w, const Arith<E>& ar, E& sum, E& dif) {
+    if constexpr (LAZY) {
+      const u64 u = fold(left, ar.k, ar.fold_c);
+      const u64 x = mul_sp_acc(u, right, w, ar.sk);
+      dif = ((u << 1) + ar.qmul[6]) - x;
+      sum = x;
+    } else if constexpr (SPLIT) {
+      const u64 x = mul_sp_acc(left, right, w, ar.sk);               // left < q, right < q
+      const u64 y = ((left << 1) + ar.qmul[5]) - x;                  // left + 5q - t'
+      sum = csub(fold(x, ar.k, ar.fold_c), ar.q);
+      dif = csub(fold(y, ar.k, ar.fold_c), ar.q);
+    } else {
+      const E t = mul_tw(right, w, ar.q);                            // :57
+      sum = csub((E)(left + t), ar.q);                               // :58
+      dif = left >= t ? (E)(left - t) : (E)(left + (ar.q - t));      // :59
+    }
+  }
+  // A^[i] * B^[i] (cg_ntt.py:88): canonical Barrett product of canonical values, or the fused kernels' lazy product (< 2q)
+  TN_HD static E pointwise(E a, E b, const Arith<E>& ar) {
+    if constexpr (LAZY) return pointwise_lazy(a, b, ar);
+    else return mulmod_barrett(a, b, ar.q, ar.mu, ar.k);
+  }
+  // canonical x * w (untwist and n^-1, cg_ntt.py:74-75,:92) / canonical x
+  TN_HD static E out_mul(E x, Tw w, const Arith<E>& ar) {
+    if constexpr (SPLIT) return P::mul_tw_canon(x, w, ar);
+    else return mul_tw(x, w, ar.q);
+  }
+  TN_HD static E out_canon(E x, const Arith<E>& ar) {
+    if constexpr (LAZY) return P::canon(x, ar);
+    else return x;
+  }
+};
+
+// One trip: NST <= L stages on the R registers of one lane-step.
+//   tw(j, h)  the record of stage j (0-based within the trip) for the butterflies whose top j bits are h
+//   SWAP      the record is MINUS the wanted twiddle (inverse transform on the forward table read backwards:
+//             omega^-i = -omega^(n/2 - i)), so the two outputs change places
+//   after(j)  called after stage j with the registers in their new places (per-stage trace)
+template <typename E, int GROUP, int AM, int NST, bool SWAP, typename TW, typename AFTER>
+TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after) {
+  constexpr int G = GROUP, L = CgGeom<G>::L;
+  typedef typename TwOf<E>::type Tw;
+  static_for<0, NST>([&](auto j_) {
+    constexpr int j = decltype(j_)::value;
+    Tw w[1 << j];
+    static_for<0, (1 << j)>([&](auto h_) { w[decltype(h_)::value] = tw(j_, h_); });
+    E z[2 * G];
+    static_for<0, G>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      if constexpr (SWAP) CgArith<E, AM>::bf(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
+      else CgArith<E, AM>::bf(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[g], z[G + g]);
+      if constexpr ((g & 1) == 1 && g + 1 < G) sched_fence();          // two butterflies in flight at a time: bounds the live temporaries
+    });
+#pragma unroll
+    for (int e = 0; e < 2 * G; ++e) x[e] = z[e];
+    after(j_);
+  });
+}
+
+// Index into the table omega^i of the record stage j of a trip needs (cg_ntt.py:51,:54: omega^(k (i // k)), k = n >> s):
+//   h (n >> (j+1)) + ((T << (L-1-j)) & ~(k - 1)),   k = n >> (s0 + j + 1)
+// for lane-step T of a trip that starts after s0 stages; (T << (L-1)) & ~((n >> (s0+1)) - 1) is computed once per trip
+// (base0) and shifted per stage.  First trip: s0 = 0 and T << (L-1) < n/2, so base0 = 0 whatever T is.
+template <int GROUP>
+TN_HD u32 cg_tw_base0(u32 logn, u32 s0, u32 T) {
+  return (T << (CgGeom<GROUP>::L - 1)) & ~((((u32)1 << logn) >> (s0 + 1)) - 1u);
+}
+
+}  // namespace tn

@@ -1,0 +1,311 @@
+// cg_kernel_impl.h — the constant-geometry kernel (K1-K5/K7 of SURVEY.md §2; BASELINE config 5) and its launcher template.
+// Included by the cg_part*.hip translation units, each of which instantiates one slice of
+// (lane width, arithmetic, lane grouping, LDS layout); cg_launch.hip picks the slice for a plan.
+//
+// The reference's dataflow (cg_ntt.py:49-64, cg_ntt_8butterfly.py:61-97) run as TRIPS of log2(2 GROUP) stages in registers
+// (cg_core.h): GROUP = 8 -> four stages per LDS round trip, three trips at n = 4096.  Per workgroup: ONE image of the
+// polynomial and the twiddle table omega^j, j <= n/2, staged in LDS once per persistent workgroup.  Twiddles that do not
+// depend on the lane (first trip; later trips while k >= 64 GROUP) are scalar loads from the L2-resident table.
+// The inverse transform of a product reads the same LDS table backwards (omega^-j = -omega^(n/2-j): the butterfly's two
+// outputs change places), so one table serves both directions.
+// Per product: read a, read b, write c in HBM; 6 LDS transposes (two per transform), 12 workgroup barriers at GROUP = 8.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "plan.h"
+#include "cg_core.h"
+#include "dev_addr.h"
+
+#ifndef TN_CG_NT_STREAM
+#define TN_CG_NT_STREAM 1        // 1: non-temporal loads/stores for the streamed operands (keeps L2 for the tables)
+#endif
+
+namespace tn {
+
+constexpr int CG_FLAG_RESTAGE = 0x100;   // or-ed into the kernel's mode: omega^(n/2) != -1 (any-psi plans): the inverse transform of a
+                                         // product reads a re-staged inverse table instead of the forward one backwards
+
+// Lane-steps one thread runs per trip.  Workgroups have n / (2 GROUP) threads up to 1024; beyond that a thread takes
+// several lane-steps (GROUP = 1: two at n = 4096).  BIG: the n = 8192 instantiations of GROUP 1 and 2 (twice the
+// lane-steps per thread; own kernels so that the n <= 4096 ones keep their register budget).
+template <typename E, int GROUP, bool BIG> struct CgShape {
+  static constexpr int R = 2 * GROUP;
+  static constexpr int MAXN = BIG ? 8192 : (GROUP >= 4 ? 8192 : 4096);
+  static constexpr int ITERS = (MAXN / R) > 1024 ? (MAXN / R) / 1024 : 1;
+  static constexpr int THREADS_MAX = (MAXN / R) > 1024 ? 1024 : (MAXN / R);
+  // waves per SIMD the register allocator leaves room for = what two workgroups per CU (the LDS limit at n = 4096 / 64-bit)
+  // amount to: GROUP 8: 2 x 256 threads -> 2 (<= 256 VGPRs: 16 coefficients, 16 of A^ and 16 prefetched per thread);
+  // GROUP 4: 2 x 512 -> 4; GROUP 1, 2: 2 x 1024 -> 8; BIG: one workgroup per CU -> 4
+  static constexpr int MIN_WAVES = BIG ? 4 : (GROUP >= 8 ? 2 : (GROUP == 4 ? 4 : 8));
+};
+
+template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
+__global__ void __launch_bounds__((CgShape<E, GROUP, BIG>::THREADS_MAX), (CgShape<E, GROUP, BIG>::MIN_WAVES))
+cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>::type* __restrict__ om_fwd,
+          const typename TwOf<E>::type* __restrict__ om_inv, const typename TwOf<E>::type* __restrict__ psi_pow,
+          const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const E* __restrict__ a, const E* __restrict__ b,
+          E* __restrict__ out, E* __restrict__ trace, u32 batch) {
+  // (the tables are separate __restrict__ arguments so that wave-uniform twiddle loads become scalar loads: see polymul_fused_kernel)
+  typedef CgGeom<GROUP> Ge;
+  typedef CgMap<E, GROUP, LAYOUT> M;
+  typedef CgArith<E, AM> A;
+  typedef typename TwOf<E>::type Tw;
+  typedef CgPair<E> Pair;
+  constexpr int R = Ge::R, L = Ge::L, ITERS = CgShape<E, GROUP, BIG>::ITERS;
+  const u32 logn = CTLOGN ? (u32)CTLOGN : logn_rt;
+  const u32 n = 1u << logn, TP = n >> L;                          // TP: lane-steps per polynomial
+  const u32 cs = logn - L;                                        // log2 TP: column e of a lane-step starts at e << cs
+  const u32 ntrips = Ge::ntrips(logn), r1 = Ge::first_stages(logn);
+  const bool big = TP >= 256;                                     // the swizzles touch index bits below 8 only: column strides keep them
+  const int mode = mode_flags & 0xff;
+  const bool restage = (mode_flags & CG_FLAG_RESTAGE) != 0;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  E* img = reinterpret_cast<E*>(tn_smem);
+  Tw* ltab = reinterpret_cast<Tw*>(img + ((M::span(n) + 3u) & ~3u));
+  auto stage_table = [&](const Tw* __restrict__ src) {            // omega^j (or omega^-j), j <= n/2
+    for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<LAYOUT>(j, big)] = src[j];
+  };
+
+  // lane-step it of this thread: threadIdx.x + it * blockDim.x.  With n compiled in the launcher starts exactly TP / ITERS
+  // threads, so every lane-step is live.
+  auto lane_step = [&](int it) -> u32 { return threadIdx.x + (u32)it * (CTLOGN ? (TP / ITERS) : blockDim.x); };
+  auto is_live = [&](int it) -> bool { return CTLOGN ? true : lane_step(it) < TP; };
+
+  // x: one lane-step's registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list, cg_ntt.py:39)
+  // -> natural order (x[e] = element ls + e TP of the transform).  glob: the table in global memory for the trips whose
+  // twiddles are wave-uniform; the LDS table is read directly, or backwards with the outputs swapped (rev).
+  auto transform = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) {
+    // opaque zero / thread index: keep the (loop-invariant) uniform twiddle loads and per-column LDS addresses of a transform
+    // inside the persistent row loop instead of in registers across it (see polymul_fused_kernel)
+    const u32 zero = opaque_zero();
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      const u32 lsi = opaque_copy(lane_step(it));
+      const u32 T = logn > (u32)L ? __brev(lsi) >> (32 - (logn - L)) : 0u;      // first trip: thread t plays lane-step brv(t) (cg_core.h)
+      auto first = [&](auto nst_) {
+        constexpr int NST = decltype(nst_)::value;
+        cg_trip<E, GROUP, AM, NST, false>(x[it], ar,
+          [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + zero]; },
+          [&](auto j_) {
+            if constexpr (AM != CGA_SPLIT_LAZY) {
+              if (tr) {
+#pragma unroll
+                for (int e = 0; e < R; ++e) tr[(size_t)decltype(j_)::value * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[it][e];
+              }
+            }
+          });
+        if (ntrips > 1) {
+#pragma unroll
+          for (int e = 0; e < R; ++e) img[M::at(Ge::pos(logn, NST, T, e))] = x[it][e];
+        }
+      };
+      if (r1 == (u32)L) first(std::integral_constant<int, L>());
+      else if constexpr (L >= 2) {
+        if (r1 == 1) first(std::integral_constant<int, 1>());
+        else if constexpr (L >= 3) {
+          if (r1 == 2) first(std::integral_constant<int, 2>());
+          else if constexpr (L >= 4) first(std::integral_constant<int, 3>());
+        }
+      }
+    }
+    u32 s0 = r1;
+    for (u32 trip = 1; trip < ntrips; ++trip, s0 += L) {
+      __syncthreads();                                             // the columns are in the image
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        const u32 base = M::at((u32)R * opaque_copy(lane_step(it)));
+#pragma unroll
+        for (int e = 0; e < R; e += 2) {
+          const Pair v = *reinterpret_cast<const Pair*>(img + M::step(base, e));
+          x[it][e] = v.lo; x[it][e + 1] = v.hi;
+        }
+      }
+      __syncthreads();                                             // everyone has read: the image may be overwritten
+      const bool uniform = (int)logn - (int)s0 - L >= 6;           // the trip's twiddles depend on (lane-step >> 6) only
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        const u32 T = opaque_copy(lane_step(it)), base0 = cg_tw_base0<GROUP>(logn, s0, T);
+        auto after = [&](auto j_) {
+          if constexpr (AM != CGA_SPLIT_LAZY) {
+            if (tr) {
+#pragma unroll
+              for (int e = 0; e < R; ++e) tr[(size_t)(s0 + decltype(j_)::value) * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[it][e];
+            }
+          }
+        };
+        if (uniform) {
+          const u32 ub = wave_uniform(base0) + zero;
+          cg_trip<E, GROUP, AM, L, false>(x[it], ar,
+            [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (ub >> decltype(j_)::value)]; }, after);
+        } else if (rev) {
+          cg_trip<E, GROUP, AM, L, true>(x[it], ar,
+            [&](auto j_, auto h_) {
+              return ltab[cg_twmap<LAYOUT>((n >> 1) - ((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value)), big)];
+            }, after);
+        } else {
+          cg_trip<E, GROUP, AM, L, false>(x[it], ar,
+            [&](auto j_, auto h_) {
+              return ltab[cg_twmap<LAYOUT>((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value), big)];
+            }, after);
+        }
+        if (trip + 1 < ntrips) {
+#pragma unroll
+          for (int e = 0; e < R; ++e) img[M::at(T + ((u32)e << cs))] = x[it][e];
+        }
+      }
+    }
+  };
+
+  // Operand and table accesses are "uniform base (row, column e: scalar unit) + the lane-step as a 32-bit offset"; the
+  // lane-step is taken through opaque_copy per use so that base + offset is not a loop invariant of the row loop
+  // (hoisted, every column's address is a 64-bit VGPR pair that lives across the whole loop: polymul_fused_kernel).
+  // raw words of one row: x[it][e] = in[row n + ls + e TP] (unit stride across lanes)
+  auto load_row = [&](E (&x)[ITERS][R], const E* __restrict__ in, u32 row) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      const u32 tl = opaque_copy(lane_step(it));
+#pragma unroll
+      for (int e = 0; e < R; ++e) {
+        const TN_GLOBAL_AS E* cp = uniform_ptr(in + ((size_t)row << logn) + ((u32)e << cs));
+#if TN_CG_NT_STREAM
+        x[it][e] = __builtin_nontemporal_load(cp + tl);
+#else
+        x[it][e] = cp[tl];
+#endif
+      }
+    }
+  };
+  // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order
+  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], bool twisted) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      const u32 tl = opaque_copy(lane_step(it));
+      if (twisted) {
+        static_for<0, R>([&](auto e_) {
+          constexpr int e = decltype(e_)::value;
+          const TN_GLOBAL_AS Tw* cp = uniform_ptr(psi_pow + ((u32)e << cs));
+          y[it][Ge::brvL(e)] = A::in_mul(x[it][e], *(const Tw*)(cp + tl), ar);      // (generic pointer for the host pass; the access stays global_load)
+        });
+      } else {
+        static_for<0, R>([&](auto e_) { constexpr int e = decltype(e_)::value; y[it][Ge::brvL(e)] = A::in_red(x[it][e], ar); });
+      }
+    }
+  };
+  // out[row n + ls + e TP] = x[e] * (psi^-(ls + e TP) n^-1)   (kind 2; cg_ntt.py:74-75 and :91-92 in one exact product),
+  //                          x[e] * n^-1 (kind 1; :74-75),  canonical x[e] (kind 0)
+  const Tw ninv = AM == CGA_SHOUP ? ar.ninv : ar.fninv;            // n^-1 in the record format of the plan's tables
+  auto store_row = [&](const E (&x)[ITERS][R], u32 row, int kind) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      const u32 tl = opaque_copy(lane_step(it));
+      E v[R];
+      if (kind == 2) {
+        static_for<0, R>([&](auto e_) {
+          constexpr int e = decltype(e_)::value;
+          const TN_GLOBAL_AS Tw* cp = uniform_ptr(psi_inv_ninv + ((u32)e << cs));
+          v[e] = A::out_mul(x[it][e], *(const Tw*)(cp + tl), ar);
+        });
+      } else if (kind == 1) {
+#pragma unroll
+        for (int e = 0; e < R; ++e) v[e] = A::out_mul(x[it][e], ninv, ar);
+      } else {
+#pragma unroll
+        for (int e = 0; e < R; ++e) v[e] = A::out_canon(x[it][e], ar);
+      }
+#pragma unroll
+      for (int e = 0; e < R; ++e) {
+        TN_GLOBAL_AS E* cp = uniform_ptr(out + ((size_t)row << logn) + ((u32)e << cs));
+#if TN_CG_NT_STREAM
+        __builtin_nontemporal_store(v[e], cp + tl);
+#else
+        cp[tl] = v[e];
+#endif
+      }
+    }
+  };
+
+  const bool product = mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL;
+  stage_table(mode == CG_NTT_INV ? om_inv : om_fwd);
+  __syncthreads();
+
+  // Persistent workgroup over rows blockIdx.x, + gridDim.x, ...; the next row's first operand is requested from HBM
+  // before the last transform of the current row and consumed at the top of the next iteration.
+  E xa[ITERS][R], xn[ITERS][R];
+  u32 row = blockIdx.x;
+  if (row < batch) load_row(xn, a, row);
+  for (; row < batch; row += gridDim.x) {
+    const u32 next = row + gridDim.x;
+    const u32 nrow = next < batch ? next : row;                    // (after the last row this row is read again and dropped: no branch around the prefetch)
+    if (!product) {
+      E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
+      enter(xa, xn, mode == CG_TWIST_FWD);
+      load_row(xn, a, nrow);
+      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, 1); }       // cg_intt: cg_ntt.py:68-75
+      else { transform(xa, om_fwd, false, tr); store_row(xa, row, 0); }
+    } else {
+      // nwc_poly_mult (cg_ntt.py:78-92); CG_CYCLIC_POLYMUL: the same chain without twist / untwist = python_poly_mult
+      // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
+      const bool twisted = mode != CG_CYCLIC_POLYMUL;
+      E xb[ITERS][R];
+      load_row(xb, b, row);                                        // in flight while a is transformed
+      enter(xa, xn, twisted);                                      // :82
+      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
+      enter(xn, xb, twisted);                                      // :83
+      transform(xn, om_fwd, false, nullptr);                       // :87
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        static_for<0, R>([&](auto e_) {                            // :88, left in the inverse's first-trip order (bit_reverse_list of :73)
+          constexpr int e = decltype(e_)::value;
+          xb[it][Ge::brvL(e)] = A::pointwise(xa[it][e], xn[it][e], ar);
+          if constexpr ((e & 1) == 1) sched_fence();               // two products in flight at a time
+        });
+      }
+      load_row(xn, a, nrow);
+      if (restage) { __syncthreads(); stage_table(om_inv); }       // (the transform's first barrier orders the staging before its first read)
+      transform(xb, om_inv, !restage, nullptr);                    // :90 (:72-73)
+      store_row(xb, row, twisted ? 2 : 1);
+      if (restage) { __syncthreads(); stage_table(om_fwd); }
+    }
+  }
+}
+
+// Launch one slice.  Returns hipErrorInvalidValue for shapes the instantiation cannot run (the dispatcher in cg_launch.hip
+// only asks for valid ones).
+template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
+static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
+                              hipStream_t s) {
+  typedef CgMap<E, GROUP, LAYOUT> M;
+  typedef CgShape<E, GROUP, BIG> Sh;
+  typedef typename TwOf<E>::type Tw;
+  const u32 n = p->n, logn = p->logn;
+  if ((int)logn < CgGeom<GROUP>::L || (CTLOGN && (int)logn != CTLOGN)) return hipErrorInvalidValue;
+  const u32 tp = n / Sh::R;
+  u32 threads = tp < 64 ? 64 : (tp > (u32)Sh::THREADS_MAX ? (u32)Sh::THREADS_MAX : tp);
+  if ((tp + threads - 1) / threads > (u32)Sh::ITERS) return hipErrorInvalidValue;
+  const size_t lds_bytes = (size_t)((M::span(n) + 3u) & ~3u) * sizeof(E) + (size_t)(n / 2 + 1) * sizeof(Tw);
+  auto kern = cg_kernel<E, GROUP, LAYOUT, AM, BIG, CTLOGN>;
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  int per_cu = 0;
+  hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)threads, lds_bytes);
+  if (qe != hipSuccess || per_cu < 1) per_cu = 1;
+  const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
+  const u32 grid = (u32)(batch < resident ? batch : resident);
+  const PlanView<E> pv = make_view<E>(p);
+  if (p->general) mode |= CG_FLAG_RESTAGE;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, pv.ar, logn, mode, pv.omega_pow, pv.omega_inv_pow, pv.psi_pow,
+                     pv.psi_inv_ninv, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch);
+  return hipGetLastError();
+}
+
+}  // namespace tn

@@ -9,16 +9,13 @@
 //      HBM traffic per product = read a, read b, write c.
 //  ntt_fused_kernel     : the standalone transforms (twist+forward, cg_ntt, cg_intt)
 //      on the same machinery, natural order in and out.
-//  cg_kernel            : K1-K5/K7, the reference's own constant-geometry
-//      dataflow (cg_ntt.py:49-64) held in two LDS ping-pong images; canonical
-//      arithmetic at every step when a trace is taken, so each stage's output
-//      equals the reference's list `A`; GROUP = butterflies issued per lane-step
-//      (8 = cg_ntt_8butterfly.py), LAYOUT = linear / padded / XOR-swizzled image
-//      (the LDS-bank-conflict sweep of BASELINE config 5).
+//  cg_kernel            : K1-K5/K7, the reference's own constant-geometry dataflow (cg_ntt.py:49-64): cg_kernel_impl.h,
+//      instantiated in slices by cg_part.hip; only the dispatcher launch_cg() lives here.
 //  fill_lcg_kernel / checksum_kernel : the reference benchmark's input
 //      generator and digest (benchmark_ntt_60bit.cpp:79-87,182-188), on device.
 #include <hip/hip_runtime.h>
 #include "plan.h"
+#include "dev_addr.h"
 
 #ifndef TN_ABL_NO_BARRIER
 #define TN_ABL_NO_BARRIER 0      // timing ablation: cross-wave transposes without workgroup barriers (wrong results)
@@ -207,20 +204,6 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
 }
 
 template <typename E> struct alignas(2 * sizeof(E)) PairOf { E lo, hi; };
-
-// A global-memory pointer the compiler must keep in scalar registers (both halves through wave_uniform): the access it
-// bases is then "scalar base + 32-bit thread offset" (global_load ... v_off, s[base]) and the base arithmetic stays on
-// the scalar unit.  (The explicit address space keeps the access a global_* instruction after the integer round trip.)
-#define TN_GLOBAL_AS __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ TN_GLOBAL_AS T* uniform_ptr(T* p) {
-#if TN_SADDR
-  const unsigned long long v = (unsigned long long)p;
-  return (TN_GLOBAL_AS T*)(((unsigned long long)wave_uniform((u32)(v >> 32)) << 32) | wave_uniform((u32)v));
-#else
-  return (TN_GLOBAL_AS T*)p;
-#endif
-}
 
 template <typename E, typename Cfg>
 __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 tau, int r) {
@@ -528,11 +511,11 @@ static hipError_t launch_nttf_t(const tn_plan* p, int mode, const void* in, void
   const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const E* in_ = (const E*)in; E* out_ = (E*)out; u32 b32 = (u32)batch;
   SchedSlot slot;
-  if (rp.dynamic) slot = sched_acquire(p);
+  if (rp.dynamic) slot = sched_acquire(p, s);
   u32* sched = slot.ptr;
   void* args[] = {&ar, &tab, &in_, &out_, &b32, &sched, &chunk};
   const hipError_t le = hipLaunchKernel(kern, dim3(grid), dim3(Cfg::THREADS), args, lds_bytes, s);
-  sched_release(p, slot, s);
+  sched_release(p, slot, s, le == hipSuccess);
   return le;
 }
 
@@ -588,12 +571,12 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   if (cyclic) ar.fninv_w1 = ar.fninv;
   // one counter pair per launch in flight (ring; each pair is re-armed by the kernel that used it)
   SchedSlot slot;
-  if (rp.dynamic) slot = sched_acquire(p);
+  if (rp.dynamic) slot = sched_acquire(p, s);
   u32* sched = slot.ptr;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds_bytes, s, ar, cyclic ? pv.cyc_brv : pv.psi_brv,
                      cyclic ? pv.cyc_inv_brv : pv.psi_inv_brv, (const E*)a, (const E*)b, (E*)c, (u32)batch, sched, chunk);
   const hipError_t le = hipGetLastError();
-  sched_release(p, slot, s);
+  sched_release(p, slot, s, le == hipSuccess);
   return le;
 }
 
@@ -628,337 +611,31 @@ const char* fused_kernel_name(const tn_plan* p) {
 }
 
 // ============================================================================
-// Constant-geometry kernel (reference dataflow, canonical arithmetic)
+// Constant-geometry kernels: dispatch to the slices of cg_part.hip (cg_kernel_impl.h)
 // ============================================================================
-// LDS image of one polynomial.  LAYOUT:
-//   CG_LINEAR   element x at x.
-//   CG_PADDED   16 bytes of padding after every 2*GROUP elements (one lane-step's contiguous read).
-//   CG_SWIZZLED x ^ (((x >> 4) & 15) << 1) ^ (((x >> 9) & 7) << 1): pairs (2i, 2i+1) stay adjacent and 16-byte aligned (bit 0
-//               untouched), and every access pattern of the sweep is bank-conflict free in the gfx950 banking model of
-//               tests/test_lds_banks.py (found by exhaustive search, tools/cg_layout_search.py): the 128-bit pair reads, the two
-//               output streams i and i + n/2 (64-bit stores at GROUP = 1, 128-bit stores of two neighbours at GROUP >= 2),
-//               the bit-reversed 128-bit scatter of the loads, and the 128-bit linear read-out; only GROUP = 2 keeps a 2-way
-//               conflict on its pair reads.
-enum CgLayout { CG_LINEAR = 0, CG_PADDED = 1, CG_SWIZZLED = 2 };
-template <typename E, int GROUP, int LAYOUT> struct CgMap {
-  static constexpr u32 CH = 2 * GROUP, PADE = 16 / sizeof(E);
-  __device__ __forceinline__ static u32 at(u32 x) {
-    if (LAYOUT == CG_PADDED) return x + (x / CH) * PADE;
-    if (LAYOUT == CG_SWIZZLED) return x ^ (((x >> 4) & 15u) << 1) ^ (((x >> 9) & 7u) << 1);
-    return x;
-  }
-  __host__ __device__ static constexpr u32 span(u32 n) { return LAYOUT == CG_PADDED ? n + (n / CH) * PADE : n; }
-  // at(x + d) from at(x) for x a multiple of a power of two > d, d < 16 (x, x + d inside one padding chunk): the swizzle
-  // only XORs bits 1..4 with functions of bits >= 4, so it commutes with setting low bits
-  __device__ __forceinline__ static u32 step(u32 ax, u32 d) { return LAYOUT == CG_SWIZZLED ? (ax ^ d) : (ax + d); }
-};
+#define TN_CG_PART_DECL(k) hipError_t launch_cg_part##k(const tn_plan*, int, int, int, bool, const void*, const void*, void*, void*, size_t, hipStream_t)
+TN_CG_PART_DECL(0); TN_CG_PART_DECL(1); TN_CG_PART_DECL(2); TN_CG_PART_DECL(3); TN_CG_PART_DECL(4); TN_CG_PART_DECL(5); TN_CG_PART_DECL(6);
+#undef TN_CG_PART_DECL
 
-// two neighbouring coefficients (2i, 2i+1): one 16-byte (8-byte for 32-bit lanes) LDS access in every layout
-template <typename E> struct alignas(2 * sizeof(E)) CgPair { E lo, hi; };
-
-// The reference butterfly with CANONICAL inputs and outputs (cg_ntt.py:57-59): t = omega * right, (left + t) % q, (left - t) % q.
-// SPLIT (64-bit lanes, q = 2^k - c: the plan's tables hold split constants, modarith.h): the product rides the multiply-add
-// chain as left + t' with t' < 5q, the difference is left + 5q - t'; one fold (-> below 2q) and one conditional
-// subtraction make each canonical.  Otherwise: Shoup product and compare-select (any odd q).
-template <typename E, bool SPLIT>
-__device__ __forceinline__ void cg_butterfly(E left, E right, typename TwOf<E>::type w, const Arith<E>& ar, E& sum, E& dif) {
-  if constexpr (SPLIT) {
-    const u64 x = mul_sp_acc(left, right, w, ar.sk);                // left < q, right < q: t' < 2^(k+1) + q/8 + 2^(k+1) + eps < 5q
-    const u64 y = ((left << 1) + ar.qmul[5]) - x;                  // left + 5q - t'
-    sum = csub(fold(x, ar.k, ar.fold_c), ar.q);
-    dif = csub(fold(y, ar.k, ar.fold_c), ar.q);
-  } else {
-    const E t = mul_tw(right, w, ar.q);                             // :57
-    sum = csub((E)(left + t), ar.q);                                // :58
-    dif = left >= t ? left - t : left + (ar.q - t);                 // :59
-  }
-}
-// a * w mod q, canonical, for ANY word a (twist :82-83, untwist / n^-1 :74-75,:92); w = nullptr: a mod q
-template <typename E, bool SPLIT>
-__device__ __forceinline__ E cg_mul(E a, const typename TwOf<E>::type* w, const Arith<E>& ar) {
-  typedef Policy<E, SPLIT> P;
-  if (w) return P::mul_tw_canon(a, *w, ar);
-  if constexpr (SPLIT) return P::canon(a, ar);
-  else return mul_tw(a, ar.one, ar.q);
-}
-
-// Lazy form of the same butterfly for the SPLIT policy when no per-stage trace is asked for (outputs only congruent
-// mod q): left is folded (< 2^k + eps), the product rides the chain, the difference is 2 left + 6q - x.  With every
-// input below 7.01 * 2^k (true for canonical inputs and preserved by the butterfly: t' < 4 * 2^k + 7.01 * 2^k / 8 + eps
-// < 4.9 * 2^k <= 6q) both outputs stay below 7.01 * 2^k; h_cg_lazy_ok() replays these bounds exactly for the plan's (k, c).
-__device__ __forceinline__ void cg_butterfly_lazy(u64 left, u64 right, Tw64 w, const Arith<u64>& ar, u64& sum, u64& dif) {
-  const u64 u = fold(left, ar.k, ar.fold_c);
-  const u64 x = mul_sp_acc(u, right, w, ar.sk);
-  dif = ((u << 1) + ar.qmul[6]) - x;
-  sum = x;
-}
-
-// Lane-steps one thread runs per stage: workgroups have n/2/GROUP threads up to 1024 (launch_cg_t); beyond that a thread
-// takes several (n = 4096 / GROUP = 1: two)
-// BIG: the n = 8192 instantiation for 64-bit lanes (twice the lane-steps and pairs per thread; own kernels so that the
-// n <= 4096 ones keep their register budget)
-template <typename E, int GROUP, bool BIG = false> struct CgShape {
-  static constexpr int MAXN = (sizeof(E) == 8 && !BIG) ? 4096 : 8192;
-  static constexpr int ITERS = (MAXN / 2 / GROUP) > 1024 ? (MAXN / 2 / GROUP) / 1024 : 1;
-  static constexpr int KEEP = GROUP * ITERS;           // pairs of A^ one thread holds for the pointwise product
-  static constexpr int THREADS_MAX = (MAXN / 2 / GROUP) > 1024 ? 1024 : (MAXN / 2 / GROUP);
-  // waves per SIMD the register allocator leaves room for = what two workgroups per CU (the LDS limit) amount to:
-  // 8 for 1024-thread workgroups (<= 64 VGPRs), 4 for 512, 2 for 256 (GROUP = 8 at 64-bit: 8 butterflies and 8 pairs of A^ per thread)
-  // (BIG and the 32-bit kernels, whose per-thread arrays are sized for n = 8192: one workgroup's worth, no spills)
-  static constexpr int MIN_WAVES = (BIG || sizeof(E) == 4) ? (THREADS_MAX / 256 < 1 ? 1 : THREADS_MAX / 256)
-                                                           : (2 * THREADS_MAX / 256 < 1 ? 1 : 2 * THREADS_MAX / 256);
-};
-
-// One CG transform in LDS: src holds the bit-reversed input; log2(n) stages
-// ping-pong between src and dst; returns the buffer holding the natural-order
-// result.  (cg_ntt.py:49-64.)  If trace != nullptr every stage's output is
-// also written there ([logn][n]).  The geometry is constant: a thread's read and write addresses are the same in
-// every stage and are computed once.  LAZYB: lazy butterflies (cg_butterfly_lazy), else canonical ones.
-template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool LAZYB, bool BIG>
-__device__ E* cg_stages(E* src, E* dst, const typename TwOf<E>::type* __restrict__ omega_tab, u32 n, u32 logn,
-                        const Arith<E>& ar, E* trace) {
-  typedef CgMap<E, GROUP, LAYOUT> M;
-  typedef CgPair<E> Pair;
-  constexpr int ITERS = CgShape<E, GROUP, BIG>::ITERS;
-  const u32 pairs = n >> 1;
-  u32 rd[ITERS], wlo[ITERS], whi[ITERS];
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const u32 i0 = (threadIdx.x + (u32)it * blockDim.x) * GROUP;
-    rd[it] = M::at(2 * i0); wlo[it] = M::at(i0); whi[it] = M::at(i0 + pairs);
-  }
-  for (u32 stage = 1; stage <= logn; ++stage) {
-    const u32 k = n >> stage;                                      // cg_ntt.py:50
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const u32 i0 = (threadIdx.x + (u32)it * blockDim.x) * GROUP;
-      if (i0 >= pairs) break;
-      E left[GROUP], right[GROUP], sum[GROUP], dif[GROUP];
-#pragma unroll
-      for (int g = 0; g < GROUP; ++g) {                            // :55-56 (8 at a time: cg_ntt_8butterfly.py:70-77)
-        const Pair v = *reinterpret_cast<const Pair*>(src + M::step(rd[it], 2 * g));
-        left[g] = v.lo; right[g] = v.hi;
-      }
-#pragma unroll
-      for (int g = 0; g < GROUP; ++g) {
-        const typename TwOf<E>::type w = omega_tab[(i0 + g) & ~(k - 1)];  // omega_s^(i//k) = omega^(k*(i//k))  (:51,:54)
-        if constexpr (LAZYB) cg_butterfly_lazy(left[g], right[g], w, ar, sum[g], dif[g]);
-        else cg_butterfly<E, SPLIT>(left[g], right[g], w, ar, sum[g], dif[g]);             // :57-59
-      }
-      if (GROUP == 1) {
-        dst[wlo[it]] = sum[0];
-        dst[whi[it]] = dif[0];
-      } else {
-#pragma unroll
-        for (int g = 0; g < GROUP; g += 2) {                       // neighbours share one 16-byte store
-          Pair a; a.lo = sum[g]; a.hi = sum[g + 1];
-          Pair b; b.lo = dif[g]; b.hi = dif[g + 1];
-          *reinterpret_cast<Pair*>(dst + M::step(wlo[it], g)) = a;
-          *reinterpret_cast<Pair*>(dst + M::step(whi[it], g)) = b;
-        }
-      }
-    }
-    __syncthreads();
-    if (trace) {
-      for (u32 i = threadIdx.x; i < n; i += blockDim.x) trace[(size_t)(stage - 1) * n + i] = dst[M::at(i)];
-    }
-    E* t = src; src = dst; dst = t;                                // :63-64
-  }
-  return src;
-}
-
-// bit_reverse_list on load (cg_ntt.py:21-26,:39): reordered[rev(idx)] = f(values[idx]).  Thread t takes idx = t and
-// idx = t + n/2, whose images rev(t) = 2 rev'(t) and 2 rev'(t) + 1 (rev' over log2(n) - 1 bits) are neighbours:
-// coalesced global reads, ONE 16-byte scattered LDS write per pair.  tw == nullptr: plain reduction mod q.
-// lazy (SPLIT policy, lazy stages follow): only congruent mod q and below the lazy stages' input bound (h_cg_lazy_ok):
-// the bare split-constant product of any word, or one fold of it.
-template <typename E, bool SPLIT>
-__device__ __forceinline__ E cg_mul_lazy(E a, const typename TwOf<E>::type* w, const Arith<E>& ar) {
-  if constexpr (SPLIT) return w ? mul_sp(a, *w, ar.sk) : fold(a, ar.k, ar.fold_c);
-  else return cg_mul<E, SPLIT>(a, w, ar);
-}
-template <typename E, int GROUP, int LAYOUT, bool SPLIT>
-__device__ void cg_load_brv(E* buf, const E* __restrict__ in, const typename TwOf<E>::type* __restrict__ tw, u32 n, u32 logn,
-                            const Arith<E>& ar, bool lazy = false) {
-  typedef CgMap<E, GROUP, LAYOUT> M;
-  const u32 half = n >> 1;
-  for (u32 t = threadIdx.x; t < half; t += blockDim.x) {
-    CgPair<E> v;                                                   // twist :82-83 / implicit % of :55-58
-    if (SPLIT && lazy) {
-      v.lo = cg_mul_lazy<E, SPLIT>(in[t], tw ? tw + t : nullptr, ar);
-      v.hi = cg_mul_lazy<E, SPLIT>(in[t + half], tw ? tw + t + half : nullptr, ar);
-    } else {
-    v.lo = cg_mul<E, SPLIT>(in[t], tw ? tw + t : nullptr, ar);
-    v.hi = cg_mul<E, SPLIT>(in[t + half], tw ? tw + t + half : nullptr, ar);
-    }
-    *reinterpret_cast<CgPair<E>*>(buf + M::at(2 * (__brev(t) >> (33 - logn)))) = v;
-  }
-  __syncthreads();
-}
-
-// natural-order read-out, two coefficients per thread and step (16-byte LDS reads, coalesced 16-byte global stores);
-// out[i] = r[i] * scale[i] (per-coefficient table), else r[i] * uni (one constant), else r[i] (made canonical if `canon`:
-// lazy stages leave values only congruent mod q)
-template <typename E, int GROUP, int LAYOUT, bool SPLIT>
-__device__ void cg_store_out(E* __restrict__ out, const E* r, u32 n, const typename TwOf<E>::type* __restrict__ scale,
-                             const typename TwOf<E>::type* uni, const Arith<E>& ar, bool canon = false) {
-  typedef CgMap<E, GROUP, LAYOUT> M;
-  for (u32 i = 2 * threadIdx.x; i < n; i += 2 * blockDim.x) {
-    CgPair<E> v = *reinterpret_cast<const CgPair<E>*>(r + M::at(i));
-    if (scale) { v.lo = cg_mul<E, SPLIT>(v.lo, scale + i, ar); v.hi = cg_mul<E, SPLIT>(v.hi, scale + i + 1, ar); }
-    else if (uni) { v.lo = cg_mul<E, SPLIT>(v.lo, uni, ar); v.hi = cg_mul<E, SPLIT>(v.hi, uni, ar); }
-    else if (canon) { v.lo = cg_mul<E, SPLIT>(v.lo, nullptr, ar); v.hi = cg_mul<E, SPLIT>(v.hi, nullptr, ar); }
-    *reinterpret_cast<CgPair<E>*>(out + i) = v;
-  }
-}
-
-// A^ of the product modes waits in registers while b is transformed (two LDS images per workgroup instead of three:
-// two workgroups per CU at n = 4096 / 64-bit): thread t keeps coefficients t + k blockDim and t + k blockDim + n/2,
-// k < CgShape::KEEP.
-constexpr int CG_MODE_LAZY = 0x100;   // or-ed into the kernel's mode: lazy butterflies allowed where no trace is taken (h_cg_lazy_ok)
-template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool BIG>
-__global__ void __launch_bounds__((CgShape<E, GROUP, BIG>::THREADS_MAX), (CgShape<E, GROUP, BIG>::MIN_WAVES))
-cg_kernel(PlanView<E> pv, int mode_flags, const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* trace, u32 batch) {
-  typedef CgMap<E, GROUP, LAYOUT> M;
-  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
-  const u32 n = pv.n, logn = pv.logn, half = n >> 1;
-  const u32 span = (M::span(n) + 3u) & ~3u;
-  E* p0 = reinterpret_cast<E*>(tn_smem);
-  E* p1 = p0 + span;
-  const Arith<E> ar = pv.ar;
-  const int mode = mode_flags & 0xff;
-  constexpr bool LZ = SPLIT;                                       // lazy stages exist only for the split policy
-  const bool lazy = LZ && (mode_flags & CG_MODE_LAZY) && !trace;
-  // run one transform: lazy stages where allowed, canonical ones otherwise (always when tracing)
-  auto stages = [&](E* src, E* dst, const typename TwOf<E>::type* tab, E* tr) -> E* {
-    if constexpr (LZ) { if (lazy) return cg_stages<E, GROUP, LAYOUT, SPLIT, LZ, BIG>(src, dst, tab, n, logn, ar, nullptr); }
-    return cg_stages<E, GROUP, LAYOUT, SPLIT, false, BIG>(src, dst, tab, n, logn, ar, tr);
-  };
-  for (u32 row = blockIdx.x; row < batch; row += gridDim.x) {
-    const size_t off = (size_t)row * n;
-    E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
-    if (mode == CG_NTT_FWD || mode == CG_TWIST_FWD) {
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, mode == CG_TWIST_FWD ? pv.psi_pow : nullptr, n, logn, ar, lazy);
-      E* r = stages(p0, p1, pv.omega_pow, tr);
-      cg_store_out<E, GROUP, LAYOUT, SPLIT>(out + off, r, n, nullptr, nullptr, ar, lazy);
-    } else if (mode == CG_NTT_INV) {                               // cg_intt: cg_ntt.py:68-75
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, nullptr, n, logn, ar, lazy);
-      E* r = stages(p0, p1, pv.omega_inv_pow, nullptr);
-      cg_store_out<E, GROUP, LAYOUT, SPLIT>(out + off, r, n, nullptr, &ar.fninv, ar);              // :74-75  (fninv: n^-1 in the plan's table format)
-    } else {                                                       // nwc_poly_mult: cg_ntt.py:78-92
-      // CG_CYCLIC_POLYMUL: the same chain without twist/untwist = python_poly_mult
-      // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
-      const typename TwOf<E>::type* twist = (mode == CG_CYCLIC_POLYMUL) ? nullptr : pv.psi_pow;
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, a + off, twist, n, logn, ar, lazy);                // :82
-      E* ra = stages(p0, p1, pv.omega_pow, nullptr);                                              // :86
-      // keep A^ in registers: the pairs this thread will need for the pointwise product (t, t + n/2)
-      constexpr int KEEP = CgShape<E, GROUP, BIG>::KEEP;                // >= (n/2) / blockDim for every launch shape (launch_cg_t)
-      E ka_lo[KEEP], ka_hi[KEEP];
-#pragma unroll
-      for (int k = 0; k < KEEP; ++k) {
-        const u32 t = threadIdx.x + (u32)k * blockDim.x;
-        if (t < half) { ka_lo[k] = ra[M::at(t)]; ka_hi[k] = ra[M::at(t + half)]; }
-      }
-      __syncthreads();
-      cg_load_brv<E, GROUP, LAYOUT, SPLIT>(p0, b + off, twist, n, logn, ar, lazy);                // :83
-      E* rb = stages(p0, p1, pv.omega_pow, nullptr);                                              // :87
-      E* f2 = (rb == p0) ? p1 : p0;
-#pragma unroll
-      for (int k = 0; k < KEEP; ++k) {                                                     // :88, stored bit-reversed for :73
-        const u32 t = threadIdx.x + (u32)k * blockDim.x;
-        if (t < half) {
-          const E a0 = ka_lo[k], a1 = ka_hi[k], b0 = rb[M::at(t)], b1 = rb[M::at(t + half)];
-          CgPair<E> v;
-          if (LZ && lazy) {                                        // lazy stages on both sides: the fused kernels' lazy product (< 2q)
-            v.lo = pointwise_lazy(a0, b0, ar);
-            v.hi = pointwise_lazy(a1, b1, ar);
-          } else {
-            v.lo = mulmod_barrett(a0, b0, ar.q, ar.mu, ar.k);
-            v.hi = mulmod_barrett(a1, b1, ar.q, ar.mu, ar.k);
-          }
-          *reinterpret_cast<CgPair<E>*>(f2 + M::at(2 * (__brev(t) >> (33 - logn)))) = v;
-        }
-      }
-      __syncthreads();
-      E* rc = stages(f2, rb, pv.omega_inv_pow, nullptr);                                          // :90 (:72-73)
-      cg_store_out<E, GROUP, LAYOUT, SPLIT>(out + off, rc, n, twist ? pv.psi_inv_ninv : nullptr, &ar.fninv, ar);   // :74-75 and :91-92 in one exact product
-    }
-    __syncthreads();
-  }
-}
-
-template <typename E, int GROUP, int LAYOUT, bool SPLIT, bool BIG = false>
-static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
-                              hipStream_t s) {
-  typedef CgMap<E, GROUP, LAYOUT> M;
-  const u32 span = (M::span(p->n) + 3u) & ~3u;
-  const size_t lds_bytes = (size_t)2 * span * sizeof(E);
-  auto kern = cg_kernel<E, GROUP, LAYOUT, SPLIT, BIG>;
-  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-  if (lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-  }
-  // one lane-step per thread and stage: n/2/GROUP threads, capped (then a thread takes CgShape::ITERS lane-steps)
-  u32 threads = p->n / 2 / GROUP;
-  threads = threads < 64 ? 64 : (threads > (u32)CgShape<E, GROUP, BIG>::THREADS_MAX ? (u32)CgShape<E, GROUP, BIG>::THREADS_MAX : threads);
-  if ((p->n / 2 / GROUP + threads - 1) / threads > (u32)CgShape<E, GROUP, BIG>::ITERS ||
-      (p->n / 2 + threads - 1) / threads > (u32)CgShape<E, GROUP, BIG>::KEEP) return hipErrorInvalidValue;
-  if (SPLIT && p->cg_lazy) mode |= CG_MODE_LAZY;
-  const u32 grid = (u32)(batch < (size_t)1 << 20 ? batch : (size_t)1 << 20);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, make_view<E>(p), mode, (const E*)a, (const E*)b, (E*)out,
-                     (E*)trace, (u32)batch);
-  return hipGetLastError();
-}
-
-template <typename E, int LAYOUT, bool SPLIT>
-static hipError_t launch_cg_l(const tn_plan* p, int mode, int group, const void* a, const void* b, void* out,
-                              void* trace, size_t batch, hipStream_t s) {
-  if constexpr (sizeof(E) == 8 && LAYOUT == CG_LINEAR) {
-    if (p->n > 4096) {                                            // n = 8192 at 64-bit lanes: the BIG kernels (linear layout only)
-      switch (group) {
-        case 1: return launch_cg_t<E, 1, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
-        case 2: return launch_cg_t<E, 2, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
-        case 4: return launch_cg_t<E, 4, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
-        case 8: return launch_cg_t<E, 8, LAYOUT, SPLIT, true>(p, mode, a, b, out, trace, batch, s);
-        default: return hipErrorInvalidValue;
-      }
-    }
-  }
-  switch (group) {
-    case 1: return launch_cg_t<E, 1, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
-    case 2: return launch_cg_t<E, 2, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
-    case 4: return launch_cg_t<E, 4, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
-    case 8: return launch_cg_t<E, 8, LAYOUT, SPLIT>(p, mode, a, b, out, trace, batch, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// SPLIT: the plan's tables hold split constants (lazy plans with 64-bit lanes; every table of such a plan does)
-template <typename E, bool SPLIT>
-static hipError_t launch_cg_e(const tn_plan* p, int mode, int group, int layout, const void* a, const void* b, void* out,
-                              void* trace, size_t batch, hipStream_t s) {
-  if (p->n < 64 || (group == 1 && layout == CG_PADDED)) layout = layout == CG_SWIZZLED && p->n >= 64 ? layout : CG_LINEAR;
-  if (sizeof(E) == 8 && p->n > 4096) layout = CG_LINEAR;              // the layout only matters to the conflict sweep (n = 4096): same bits
-  if (p->n < (u32)(4 * group)) group = 1;                               // tiny n: the grouped store pairs assume n >= 4 GROUP
-  switch (layout) {
-    case CG_LINEAR: return launch_cg_l<E, CG_LINEAR, SPLIT>(p, mode, group, a, b, out, trace, batch, s);
-    case CG_PADDED: return launch_cg_l<E, CG_PADDED, SPLIT>(p, mode, group, a, b, out, trace, batch, s);
-    case CG_SWIZZLED: return launch_cg_l<E, CG_SWIZZLED, SPLIT>(p, mode, group, a, b, out, trace, batch, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
+// group: butterflies per lane-step (1, 2, 4, 8); layout: CgLayout.  The LDS layouts differ only where the sweep of BASELINE
+// config 5 is defined (lazy 64-bit plans at n = 4096); every other plan runs the linear image whatever the variant says.
 hipError_t launch_cg(const tn_plan* p, int mode, int group, int layout, const void* a, const void* b, void* out, void* trace,
                      size_t batch, hipStream_t s) {
   if (batch == 0) return hipSuccess;
 #ifdef TN_ONLY_MAIN
   return hipErrorInvalidValue;
 #else
-  if (p->elem_bytes == 8)
-    return p->lazy ? launch_cg_e<u64, true>(p, mode, group, layout, a, b, out, trace, batch, s)
-                   : launch_cg_e<u64, false>(p, mode, group, layout, a, b, out, trace, batch, s);
-  return launch_cg_e<u32, false>(p, mode, group, layout, a, b, out, trace, batch, s);
+  if (group != 1 && group != 2 && group != 4 && group != 8) return hipErrorInvalidValue;
+  while ((2u * (u32)group) > p->n) group /= 2;                      // tiny n: a lane-step cannot hold more than the polynomial
+  const bool big = p->n / (2u * (u32)group) > (group == 1 ? 2048u : 1024u);   // n = 8192 at GROUP 1, 2 (CgShape)
+  if (p->elem_bytes == 4) return launch_cg_part0(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  if (!(p->lazy)) return launch_cg_part1(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  // lazy 64-bit plan: every table holds split constants.  Per-stage traces need canonical values at every stage.
+  if (trace || !p->cg_lazy) return launch_cg_part2(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  if (p->logn != 12) return launch_cg_part3(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  if (group <= 2) return launch_cg_part4(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  if (group == 4) return launch_cg_part5(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  return launch_cg_part6(p, mode, group, layout, big, a, b, out, trace, batch, s);
 #endif
 }
 

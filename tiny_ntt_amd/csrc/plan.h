@@ -16,6 +16,7 @@ struct tn_plan {
   int elem_bytes = 8;
   bool has_fused = false, lazy = false, cg_lazy = false;
   bool omega_only = false;   // created by tn_plan_create_omega: no psi, only the constant-geometry transforms
+  bool general = false;      // created by tn_plan_create_general: psi / q not validated, tables computed literally (cg_ntt.py:78-92 for ANY psi)
   int k = 0;            // bitlen(q)
   tn::Arith<tn::u64> ar64 = {};    // kernel-argument constants (h_make_arith); the one matching elem_bytes is used
   tn::Arith<tn::u32> ar32 = {};
@@ -94,23 +95,37 @@ template <typename E> inline PlanView<E> make_view(const tn_plan* p) {
   return v;
 }
 
-// Dynamic-row-scheduler slot for one launch on stream s, or nullptr (fixed stride) when the ring's next slot is still in
-// use by an earlier launch (possible across streams); sched_release records the slot's event after the launch.
-struct SchedSlot { u32* ptr = nullptr; int index = -1; };
-inline SchedSlot sched_acquire(const tn_plan* p) {
+// Dynamic-row-scheduler slot for one launch on stream s, or nullptr (fixed stride, always correct) when
+//   * the stream is being captured into a graph: a captured launch would bake the slot pointer into its kernel node while
+//     the ring keeps advancing, so a later replay could share a counter pair with a live launch (rows skipped); and
+//     hipEventQuery is not allowed while capturing;
+//   * the ring's next slot is still in use by an earlier launch (possible across streams).
+// A slot counts as used only once its event HAS BEEN RECORDED behind the launch (sched_release, under the same lock as the
+// hand-out): sched_acquire returns with the lock held and sched_release drops it, so no other thread can see a slot that
+// is handed out but whose event does not yet cover the launch.
+struct SchedSlot { u32* ptr = nullptr; int index = -1; bool locked = false; };
+inline SchedSlot sched_acquire(const tn_plan* p, hipStream_t stream) {
   SchedSlot r;
   if (!p->d_sched) return r;
-  std::lock_guard<std::mutex> g(p->sched_mu);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return r;
+  p->sched_mu.lock();
   const unsigned i = p->sched_seq % tn_plan::SCHED_SLOTS;
-  if (p->sched_used[i] && hipEventQuery(p->sched_ev[i]) != hipSuccess) return r;     // still running (or errored): do not share it
-  if (!p->sched_ev[i] && hipEventCreateWithFlags(&p->sched_ev[i], hipEventDisableTiming) != hipSuccess) return r;
-  ++p->sched_seq;
-  p->sched_used[i] = true;
-  r.ptr = p->d_sched + 2 * i; r.index = (int)i;
+  bool ok = !(p->sched_used[i] && hipEventQuery(p->sched_ev[i]) != hipSuccess);       // still running (or errored): do not share it
+  if (ok && !p->sched_ev[i]) ok = hipEventCreateWithFlags(&p->sched_ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { p->sched_mu.unlock(); return r; }
+  r.ptr = p->d_sched + 2 * i; r.index = (int)i; r.locked = true;
   return r;
 }
-inline void sched_release(const tn_plan* p, const SchedSlot& s, hipStream_t stream) {
-  if (s.index >= 0) (void)hipEventRecord(p->sched_ev[s.index], stream);
+// launched: the kernel that uses the slot was enqueued (a failed launch leaves the slot free and the ring where it was)
+inline void sched_release(const tn_plan* p, const SchedSlot& s, hipStream_t stream, bool launched = true) {
+  if (!s.locked) return;
+  if (launched) {
+    if (hipEventRecord(p->sched_ev[s.index], stream) == hipSuccess) p->sched_used[s.index] = true;
+    else (void)hipStreamSynchronize(stream);       // nothing can tell later when the kernel has finished: wait for it now, the slot stays free
+    ++p->sched_seq;
+  }
+  p->sched_mu.unlock();
 }
 
 // kernels.hip

@@ -199,8 +199,8 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   std::vector<u64>& psi_inv_pow = t.psi_inv_pow;
   psi_inv_pow.resize(n);
   t.psi_pow.resize(n); t.psi_inv_ninv.resize(n); t.psi_brv.resize(n); t.psi_inv_brv.resize(n);
-  t.omega_pow.resize(n / 2); t.omega_inv_pow.resize(n / 2);
-  u64 f = 1, g = 1;
+  t.omega_pow.resize(n / 2 + 1); t.omega_inv_pow.resize(n / 2 + 1);      // one entry more than cg_ntt.py uses: omega^(n/2) = -1,
+  u64 f = 1, g = 1;                                                          // so that omega^-i = -omega^(n/2 - i) for EVERY i < n/2 (cg_core.h)
   for (u32 i = 0; i < n; ++i) { t.psi_pow[i] = f; psi_inv_pow[i] = g; f = h_mulmod(f, t.psi, q); g = h_mulmod(g, psi_inv, q); }
   for (u32 i = 0; i < n; ++i) {
     t.psi_brv[i] = t.psi_pow[h_brv(i, logn)];
@@ -216,7 +216,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
     t.cyc_inv_brv[i] = psi_inv_pow[e];
   }
   u64 w = 1, wi = 1;
-  for (u32 j = 0; j < n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
+  for (u32 j = 0; j <= n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
   t.ninv_w1 = h_mulmod(t.n_inv, t.psi_inv_brv[1], q);
   return t;
 }
@@ -235,9 +235,9 @@ inline HostTables h_build_omega_tables(u32 n, u64 q, u64 omega) {
   t.lazy = false; t.cg_lazy = false; t.fold_c = 0;
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);             // modinv(omega_n): cg_ntt.py:9-10, :72
   t.n_inv = h_powmod(n % q, q - 2, q);                           // :74
-  t.omega_pow.resize(n / 2); t.omega_inv_pow.resize(n / 2);
+  t.omega_pow.resize(n / 2 + 1); t.omega_inv_pow.resize(n / 2 + 1);
   u64 w = 1 % q, wi = 1 % q;
-  for (u32 j = 0; j < n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
+  for (u32 j = 0; j <= n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
   t.ninv_w1 = t.n_inv;
   return t;
 }
