@@ -221,17 +221,18 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
   constexpr int R = Ge::R, L = Ge::L;
   const u32 n = t.n, logn = t.logn;
   if ((int)logn < L) return 7;
-  if (trace && AM == CGA_SPLIT_LAZY) return 7;
+  if (trace && (AM == CGA_SPLIT_LAZY || AM == CGA_SPLIT_SCHED)) return 7;
+  if (AM == CGA_SPLIT_SCHED && !t.cg_sched) return 7;
   const Arith<E> ar = h_make_arith<E>(t);
   const u32 TP = n >> L, ntrips = Ge::ntrips(logn), r1 = Ge::first_stages(logn);
   const bool split = AM != CGA_SHOUP;
   auto table = [&](const std::vector<u64>& v) { return split ? h_fused_table<E>(v, t) : h_tw_table<E>(v, t.q); };
   const std::vector<Tw> fwd = table(t.omega_pow), inv = table(t.omega_inv_pow), psi_pow = table(t.psi_pow), psi_inv_ninv = table(t.psi_inv_ninv);
   const Tw ninv = split ? ar.fninv : ar.ninv;
-  const bool big = TP >= 256;
+  const bool big = n >= 512;
   std::vector<E> img(M::span(n) + 4, (E)0xDEADBEEFu);
   std::vector<Tw> ldstab(n / 2 + 1);
-  auto stage_table = [&](const std::vector<Tw>& g) { for (u32 j = 0; j <= n / 2; ++j) ldstab[cg_twmap<LAYOUT>(j, big)] = g[j]; };
+  auto stage_table = [&](const std::vector<Tw>& g) { for (u32 j = 0; j <= n / 2; ++j) ldstab[cg_twmap<GROUP, LAYOUT>(j, big)] = g[j]; };
   struct Regs { E x[R]; };
 
   // x: registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list) -> natural order (x[e] = output ls + e TP)
@@ -263,9 +264,13 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
         const u32 T = ls, base0 = cg_tw_base0<GROUP>(logn, s0, T);
         auto after = [&](auto j_) { if (tr) for (u32 e = 0; e < (u32)R; ++e) tr[(size_t)(s0 + decltype(j_)::value) * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[ls].x[e]; };
         auto idx = [&](int j, u32 h) { return h * (n >> (j + 1)) + (base0 >> j); };
-        if (uniform) cg_trip<E, GROUP, AM, L, false>(x[ls].x, ar, [&](auto j_, auto h_) { return glob[idx(decltype(j_)::value, decltype(h_)::value)]; }, after);
-        else if (rev) cg_trip<E, GROUP, AM, L, true>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<LAYOUT>(n / 2 - idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
-        else cg_trip<E, GROUP, AM, L, false>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<LAYOUT>(idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
+        auto run = [&](auto par_) {
+          constexpr int PAR = decltype(par_)::value;
+          if (uniform) cg_trip<E, GROUP, AM, L, false, PAR>(x[ls].x, ar, [&](auto j_, auto h_) { return glob[idx(decltype(j_)::value, decltype(h_)::value)]; }, after);
+          else if (rev) cg_trip<E, GROUP, AM, L, true, PAR>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<GROUP, LAYOUT>(n / 2 - idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
+          else cg_trip<E, GROUP, AM, L, false, PAR>(x[ls].x, ar, [&](auto j_, auto h_) { return ldstab[cg_twmap<GROUP, LAYOUT>(idx(decltype(j_)::value, decltype(h_)::value), big)]; }, after);
+        };
+        if (AM == CGA_SPLIT_SCHED && (s0 & 1u)) run(std::integral_constant<int, 1>()); else run(std::integral_constant<int, 0>());
       }
       if (trip + 1 < ntrips) for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) img[M::at(Ge::pos(logn, L, ls, e))] = x[ls].x[e];
     }
@@ -375,18 +380,28 @@ int emu_cg(uint32_t n, uint64_t q, uint64_t psi, int mode, const uint64_t* a, co
 }
 
 // The trips of cg_kernels.hip stepped on the CPU.  am: 0 Shoup records, 1 split records canonical, 2 split records lazy
-// (1 and 2 need a plan that is lazy with 64-bit lanes).  7 = unsupported combination.
+// 3 split records lazy with the static fold schedule (1, 2, 3 need a plan that is lazy with 64-bit lanes; 3 an even log2 n).  7 = unsupported combination.
 int emu_cgm(uint32_t n, uint64_t q, uint64_t psi, int mode, int group, int layout, int am, int flags, const uint64_t* a,
             const uint64_t* b, uint64_t* out, uint64_t* trace) {
   if (!params_ok(n, q, psi)) return 2;
   const HostTables t = h_build_tables(n, q, psi, true);
-  if (am != 0 && !(t.lazy && t.elem_bytes == 8 && (am == 1 || t.cg_lazy))) return 7;
+  if (am < 0 || am > 3 || (am != 0 && !(t.lazy && t.elem_bytes == 8 && (am == 1 || t.cg_lazy)))) return 7;
   if (t.elem_bytes == 8) {
     if (am == 0) return cgm_dispatch<u64, CGA_SHOUP>(t, mode, group, layout, flags, a, b, out, trace);
     if (am == 1) return cgm_dispatch<u64, CGA_SPLIT_CANON>(t, mode, group, layout, flags, a, b, out, trace);
-    return cgm_dispatch<u64, CGA_SPLIT_LAZY>(t, mode, group, layout, flags, a, b, out, trace);
+    if (am == 2) return cgm_dispatch<u64, CGA_SPLIT_LAZY>(t, mode, group, layout, flags, a, b, out, trace);
+    return cgm_dispatch<u64, CGA_SPLIT_SCHED>(t, mode, group, layout, flags, a, b, out, trace);
   }
   return cgm_dispatch<u32, CGA_SHOUP>(t, mode, group, layout, flags, a, b, out, trace);
+}
+
+// Layout probes of the constant-geometry kernels (64-bit lanes): what 0 = CgMap::at(x), 1 = cg_twmap(x) (n >= 512), 2 = CgMap::span(x)
+long emu_cgm_probe(int group, int layout, int what, unsigned x) {
+#define TN_CGP(G, LY) if (group == G && layout == LY) return what == 0 ? (long)CgMap<u64, G, LY>::at(x) : what == 1 ? (long)cg_twmap<G, LY>(x, true) : (long)CgMap<u64, G, LY>::span(x);
+  TN_CGP(1, 0) TN_CGP(1, 1) TN_CGP(1, 2) TN_CGP(2, 0) TN_CGP(2, 1) TN_CGP(2, 2)
+  TN_CGP(4, 0) TN_CGP(4, 1) TN_CGP(4, 2) TN_CGP(8, 0) TN_CGP(8, 1) TN_CGP(8, 2)
+#undef TN_CGP
+  return -1;
 }
 
 // see cfg_probe() above for `what`

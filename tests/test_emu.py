@@ -87,7 +87,7 @@ def test_cg_trips_emulation_matches_golden_and_oracle(emu, oracle, golden, tag):
     ran = 0
     for group in (1, 2, 4, 8):
         for layout in (0, 1, 2):
-            for am in (0, 1, 2):
+            for am in (0, 1, 2, 3):
                 if emu.cgm(n, q, psi, 0, a, group=group, layout=layout, am=am) is None:
                     continue                                  # log2 n < log2(2 group), or split arithmetic on a Shoup plan
                 ran += 1
@@ -96,7 +96,7 @@ def test_cg_trips_emulation_matches_golden_and_oracle(emu, oracle, golden, tag):
                 for name in g.cases("poly_mult"):
                     assert np.array_equal(emu.cgm(n, q, psi, 2, g[name + "_a"], g[name + "_b"], group=group, layout=layout, am=am), g[name + "_c"]), name
                 for name in g.cases("ntt"):
-                    if am != 2:                               # traces need canonical stages
+                    if am < 2:                                # traces need canonical stages
                         out, tr = emu.cgm(n, q, psi, 0, g[name + "_x"], group=group, layout=layout, am=am, flags=1, trace=True)
                         assert np.array_equal(out, g[name + "_X"]) and np.array_equal(tr, full_trace[name]), (name, group, layout, am)
                         assert np.array_equal(tr[:, :min(16, n)], g[name + "_trace16"]), name
@@ -119,7 +119,7 @@ def test_cg_trips_emulation_every_size(emu, oracle):
             a = rng.integers(0, q, n, dtype=np.uint64); b = rng.integers(0, q, n, dtype=np.uint64)
             ref = oracle.poly_mult(a[None], b[None], q, psi)[0]
             for group in (1, 2, 4, 8):
-                for am in (0, 1, 2):
+                for am in (0, 1, 2, 3):
                     c = emu.cgm(n, q, psi, 2, a, b, group=group, layout=2 if group & 5 else 1, am=am, flags=1)
                     assert c is None or np.array_equal(c, ref), (n, q, group, am)
 

@@ -130,3 +130,30 @@ def test_every_other_shape_is_conflict_free_too(probe):
         cfg = Cfg(probe, logn, eb)
         for key, (w, r) in worst_degrees(cfg).items():
             assert (w, r) == (1, 1), (logn, eb, key, w, r)
+
+
+def test_constant_geometry_layouts_in_the_banking_model(probe):
+    """BASELINE config 5 (n = 4096, 64-bit lanes): the padded and the swizzled image + the swizzled LDS twiddle table are
+    conflict free for every access of the trips except the first trip's bit-reversed column writes and the table read
+    backwards (2-way each); the linear layouts are the conflicted baseline of the sweep.  The model's maps are the
+    product's (probed from cg_core.h through tests/emu)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cg_layout_search as cg
+    probe.lib.emu_cgm_probe.restype = ctypes.c_long
+    probe.lib.emu_cgm_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    for G in (1, 2, 4, 8):
+        for layout in (0, 1, 2):
+            at, tw = cg.image_map(G, layout), cg.table_map(G, layout)
+            assert all(probe.lib.emu_cgm_probe(G, layout, 0, x) == at(x) for x in range(4096)), (G, layout)
+            assert all(probe.lib.emu_cgm_probe(G, layout, 1, j) == tw(j) for j in range(2049)), (G, layout)
+            span = probe.lib.emu_cgm_probe(G, layout, 2, 4096)
+            assert len({at(x) for x in range(4096)}) == 4096 and max(at(x) for x in range(4096)) < span
+            assert len({tw(j) for j in range(2049)}) == 2049 and max(tw(j) for j in range(2049)) <= 2048
+            tot, ideal, worst = cg.score(G, at, tw, True)
+            if layout == 0:
+                assert tot > 1.4 * ideal, (G, tot, ideal)              # the conflicted baseline
+                continue
+            for tag, d in worst.items():
+                limit = 2 if (tag == "W1" or tag.startswith("TWr")) else 1
+                assert d <= limit, (G, layout, tag, d)

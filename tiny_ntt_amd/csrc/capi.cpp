@@ -100,7 +100,7 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   const HostTables t = h_build_tables(n, q, psi, !(flags & TN_PLAN_FORCE_CANONICAL));
   p->n = n; p->logn = logn; p->q = q; p->psi = psi; p->omega = t.omega;
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
-  p->k = t.k; p->lazy = t.lazy; p->cg_lazy = t.cg_lazy;
+  p->k = t.k; p->lazy = t.lazy; p->cg_lazy = t.cg_lazy; p->cg_sched = t.cg_sched;
   if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
   p->has_fused = fused_supported(logn, elem_bytes);
   {

@@ -29,7 +29,8 @@ enum CgLayout { CG_LINEAR = 0, CG_PADDED = 1, CG_SWIZZLED = 2 };
 // Arithmetic of the butterflies: Shoup records + compare-select (any modulus); the plan's split-constant records with
 // canonical values at every step (per-stage traces of a lazy 64-bit plan); split-constant records, values only congruent
 // mod q between stages (h_cg_lazy_ok replays the bounds for the plan's (k, c)).
-enum CgArithMode { CGA_SHOUP = 0, CGA_SPLIT_CANON = 1, CGA_SPLIT_LAZY = 2 };
+// CGA_SPLIT_SCHED: the same with a static fold schedule instead of one fold per butterfly (below; h_cg_sched_ok).
+enum CgArithMode { CGA_SHOUP = 0, CGA_SPLIT_CANON = 1, CGA_SPLIT_LAZY = 2, CGA_SPLIT_SCHED = 3 };
 
 template <int V> struct ILog2 { static constexpr int value = 1 + ILog2<V / 2>::value; };
 template <> struct ILog2<1> { static constexpr int value = 0; };
@@ -49,34 +50,57 @@ template <int GROUP> struct CgGeom {
   }
 };
 
-// LDS image of one polynomial.  LAYOUT:
+// LDS image of one polynomial.  LAYOUT (parameters per GROUP from tools/cg_layout_search.py: exhaustive search over the gfx950
+// banking model of tests/test_lds_banks.py for the accesses of the trips — 128-bit reads of a lane-step's R neighbours,
+// element-wide column writes T + e n/R for T = lane (later trips) and T = brv(lane) (first trip)):
 //   CG_LINEAR   element x at x.
-//   CG_PADDED   16 bytes of padding after every R = 2 GROUP elements (one lane-step's contiguous read).
-//   CG_SWIZZLED x ^ (((x >> 4) & 15) << 1) ^ (((x >> 9) & 7) << 1): pairs (2i, 2i+1) stay adjacent and 16-byte aligned
-//               (bit 0 untouched); chosen by search over the gfx950 banking model (tools/cg_layout_search.py,
-//               tests/test_lds_banks.py) for the accesses of the trips: 128-bit reads of a lane-step's R neighbours,
-//               element-wide column writes T + e n/R for T = lane (later trips) and T = brv(lane) (first trip).
+//   CG_PADDED   16 bytes of padding after every CH elements, CH = 16 / 32 / 64 / 64 for GROUP 8 / 4 / 2 / 1 (GROUP 1: and
+//               after every 256): additive in the lane-step and in the column, so every access is one address register
+//               plus an immediate.
+//   CG_SWIZZLED x ^ (((x >> S1) & M1) << 1) ^ (((x >> S2) & M2) << 1) ^ (((x >> S3) & M3) << 1): pairs (2i, 2i+1) stay adjacent
+//               and 16-byte aligned (bit 0 untouched, source bits all >= log2 R).
+// In both, every access of every GROUP is conflict free in the model except the first trip's bit-reversed column writes
+// (2-way: 16 lanes of a 64-bit store land on 8 pairs of banks whatever pair-preserving map is used).
+template <int GROUP> struct CgSwz;
+template <> struct CgSwz<8> { static constexpr u32 S1 = 4, M1 = 15, S2 = 9, M2 = 7, S3 = 0, M3 = 0, CH = 16, CH2 = 0, TS = 4, TM = 15; };
+template <> struct CgSwz<4> { static constexpr u32 S1 = 3, M1 = 1, S2 = 4, M2 = 7, S3 = 8, M3 = 7, CH = 32, CH2 = 0, TS = 4, TM = 7; };
+template <> struct CgSwz<2> { static constexpr u32 S1 = 2, M1 = 1, S2 = 3, M2 = 7, S3 = 7, M3 = 7, CH = 64, CH2 = 0, TS = 4, TM = 3; };
+template <> struct CgSwz<1> { static constexpr u32 S1 = 2, M1 = 1, S2 = 4, M2 = 7, S3 = 7, M3 = 7, CH = 64, CH2 = 256, TS = 1, TM = 15; };
 template <typename E, int GROUP, int LAYOUT> struct CgMap {
-  static constexpr u32 CH = 2 * GROUP, PADE = 16 / sizeof(E);
+  typedef CgSwz<GROUP> Z;
+  static constexpr u32 PADE = 16 / sizeof(E);
   TN_HD static u32 at(u32 x) {
-    if (LAYOUT == CG_PADDED) return x + (x / CH) * PADE;
-    if (LAYOUT == CG_SWIZZLED) return x ^ (((x >> 4) & 15u) << 1) ^ (((x >> 9) & 7u) << 1);
+    if (LAYOUT == CG_PADDED) return x + (x / Z::CH) * PADE + (Z::CH2 ? (x / (Z::CH2 ? Z::CH2 : 1u)) * PADE : 0u);
+    if (LAYOUT == CG_SWIZZLED) return x ^ (((x >> Z::S1) & Z::M1) << 1) ^ (((x >> Z::S2) & Z::M2) << 1) ^ (((x >> Z::S3) & Z::M3) << 1);
     return x;
   }
-  TN_HD static constexpr u32 span(u32 n) { return LAYOUT == CG_PADDED ? n + (n / CH) * PADE : n; }
-  // at(x + d) from at(x) for x a multiple of R, d < R <= 16: the swizzle only XORs bits 1..4 with functions of bits >= 4
+  TN_HD static constexpr u32 span(u32 n) { return LAYOUT == CG_PADDED ? n + (n / Z::CH) * PADE + (Z::CH2 ? (n / (Z::CH2 ? Z::CH2 : 1u)) * PADE : 0u) : n; }
+  // at(x + d) from at(x) for x a multiple of R, d < R: padding chunks are multiples of R; the swizzle only XORs bits >= 1
+  // with functions of bits >= log2 R
   TN_HD static u32 step(u32 ax, u32 d) { return LAYOUT == CG_SWIZZLED ? (ax ^ d) : (ax + d); }
+  // at(T + (e << cs)) from aT = at(T) for T < 2^cs, 2^cs a multiple of every padding chunk (n >= 4096 here): the padding is
+  // additive in the column, and the swizzle is GF(2)-linear (at(T ^ C) = at(T) ^ at(C)) with T + C = T ^ C for a column start C, so a column write
+  // is one address register (XORed with a per-column constant for the swizzle) plus an immediate
+  TN_HD static u32 col(u32 aT, u32 e, u32 cs) {
+    const u32 c0 = e << cs;
+    if (LAYOUT == CG_PADDED) return aT + at(c0);
+    if (LAYOUT == CG_SWIZZLED) return (aT ^ (at(c0) ^ c0)) + c0;
+    return aT + c0;
+  }
 };
-// The twiddle table omega^j, j <= n/2, staged in LDS: record j at twmap(j).  Swizzled with the image: the last trip reads it
-// at strides G, G/2, .., 1 records across lanes, and 16-byte records at a power-of-two stride hit the same banks.
-template <int LAYOUT> TN_HD u32 cg_twmap(u32 j, bool big) { return (LAYOUT == CG_SWIZZLED && big) ? (j ^ ((j >> 4) & 15u)) : j; }
+// The twiddle table omega^j, j <= n/2, staged in LDS: record j at twmap(j).  XOR-swizzled for the padded and the swizzled
+// image alike: the last trip reads it at strides G, G/2, .., 1 records across lanes, and 16-byte records at a power-of-two
+// stride hit the same banks (conflict free forwards; read backwards for the inverse a 2-way conflict remains).
+template <int GROUP, int LAYOUT> TN_HD u32 cg_twmap(u32 j, bool big) {
+  return (LAYOUT != CG_LINEAR && big) ? (j ^ ((j >> CgSwz<GROUP>::TS) & CgSwz<GROUP>::TM)) : j;
+}
 
 // two neighbouring coefficients (2i, 2i+1): one 16-byte (8-byte for 32-bit lanes) LDS access in every layout
 template <typename E> struct alignas(2 * sizeof(E)) CgPair { E lo, hi; };
 
 template <typename E, int AM> struct CgArith {
   typedef typename TwOf<E>::type Tw;
-  static constexpr bool SPLIT = AM != CGA_SHOUP, LAZY = AM == CGA_SPLIT_LAZY;
+  static constexpr bool SPLIT = AM != CGA_SHOUP, LAZY = AM == CGA_SPLIT_LAZY || AM == CGA_SPLIT_SCHED, SCHED = AM == CGA_SPLIT_SCHED;
   typedef Policy<E, SPLIT> P;
   // a * w for ANY word a (twist, cg_ntt.py:82-83) / a mod q (the implicit % of :55-58).  Canonical, or (lazy) only congruent and
   // below the lazy butterflies' input bound: the bare split-constant product, or one fold.
@@ -97,8 +121,17 @@ template <typename E, int AM> struct CgArith {
   //   split, lazy: left is folded (< 2^k + eps), the difference is 2 left + 6q - x.  With every input below 7.01 * 2^k (true
   //     for canonical inputs and preserved: t' < 4 * 2^k + 7.01 * 2^k / 8 + eps < 4.9 * 2^k <= 6q) both outputs stay below
   //     7.01 * 2^k; h_cg_lazy_ok() replays these bounds exactly for the plan's (k, c).
-  TN_HD static void bf(E left, E right, Tw w, const Arith<E>& ar, E& sum, E& dif) {
-    if constexpr (LAZY) {
+  //   split, scheduled (n = 4096 compiled in): values of an even stage's inputs are below 12.01 * 2^k, of an odd stage's below
+  //     7.01 * 2^k (the twisted / folded / pointwise inputs of stage 1 too); odd stages (STAGE_EVEN false) run on the raw left
+  //     input with the difference 2 left + 5q - x (t' < 4.9 * 2^k <= 5q, outputs below 12.01 * 2^k), even stages fold left first
+  //     and use 6q (t' < 5.51 * 2^k <= 6q, outputs below 7.01 * 2^k): half the folds.  h_cg_sched_ok() replays this exactly.
+  template <bool STAGE_EVEN> TN_HD static void bf(E left, E right, Tw w, const Arith<E>& ar, E& sum, E& dif) {
+    if constexpr (SCHED) {
+      const u64 u = STAGE_EVEN ? fold(left, ar.k, ar.fold_c) : left;
+      const u64 x = mul_sp_acc(u, right, w, ar.sk);
+      dif = ((u << 1) + ar.qmul[STAGE_EVEN ? 6 : 5]) - x;
+      sum = x;
+    } else if constexpr (LAZY) {
       const u64 u = fold(left, ar.k, ar.fold_c);
       const u64 x = mul_sp_acc(u, right, w, ar.sk);
       dif = ((u << 1) + ar.qmul[6]) - x;
@@ -135,7 +168,8 @@ template <typename E, int AM> struct CgArith {
 //   SWAP      the record is MINUS the wanted twiddle (inverse transform on the forward table read backwards:
 //             omega^-i = -omega^(n/2 - i)), so the two outputs change places
 //   after(j)  called after stage j with the registers in their new places (per-stage trace)
-template <typename E, int GROUP, int AM, int NST, bool SWAP, typename TW, typename AFTER>
+//   S0PAR     parity of the number of stages done before this trip (the scheduled arithmetic folds on even stages)
+template <typename E, int GROUP, int AM, int NST, bool SWAP, int S0PAR = 0, typename TW, typename AFTER>
 TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after) {
   constexpr int G = GROUP, L = CgGeom<G>::L;
   typedef typename TwOf<E>::type Tw;
@@ -146,9 +180,10 @@ TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after
     E z[2 * G];
     static_for<0, G>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
-      if constexpr (SWAP) CgArith<E, AM>::bf(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
-      else CgArith<E, AM>::bf(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[g], z[G + g]);
-      if constexpr ((g & 1) == 1 && g + 1 < G) sched_fence();          // two butterflies in flight at a time: bounds the live temporaries
+      constexpr bool EVEN = ((S0PAR + j + 1) & 1) == 0;                 // stage number s0 + j + 1 (cg_ntt.py:49)
+      if constexpr (SWAP) CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
+      else CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[g], z[G + g]);
+      if constexpr ((g & 1) == 1 && g + 1 < G) sched_fence_valu();     // two butterflies in flight at a time: bounds the live temporaries
     });
 #pragma unroll
     for (int e = 0; e < 2 * G; ++e) x[e] = z[e];

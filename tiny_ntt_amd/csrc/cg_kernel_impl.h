@@ -55,7 +55,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   const u32 n = 1u << logn, TP = n >> L;                          // TP: lane-steps per polynomial
   const u32 cs = logn - L;                                        // log2 TP: column e of a lane-step starts at e << cs
   const u32 ntrips = Ge::ntrips(logn), r1 = Ge::first_stages(logn);
-  const bool big = TP >= 256;                                     // the swizzles touch index bits below 8 only: column strides keep them
+  const bool big = n >= 512;                                      // the table swizzle maps record n/2 to itself from there on
   const int mode = mode_flags & 0xff;
   const bool restage = (mode_flags & CG_FLAG_RESTAGE) != 0;
 
@@ -63,7 +63,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   E* img = reinterpret_cast<E*>(tn_smem);
   Tw* ltab = reinterpret_cast<Tw*>(img + ((M::span(n) + 3u) & ~3u));
   auto stage_table = [&](const Tw* __restrict__ src) {            // omega^j (or omega^-j), j <= n/2
-    for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<LAYOUT>(j, big)] = src[j];
+    for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<GROUP, LAYOUT>(j, big)] = src[j];
   };
 
   // lane-step it of this thread: threadIdx.x + it * blockDim.x.  With n compiled in the launcher starts exactly TP / ITERS
@@ -95,10 +95,6 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
               }
             }
           });
-        if (ntrips > 1) {
-#pragma unroll
-          for (int e = 0; e < R; ++e) img[M::at(Ge::pos(logn, NST, T, e))] = x[it][e];
-        }
       };
       if (r1 == (u32)L) first(std::integral_constant<int, L>());
       else if constexpr (L >= 2) {
@@ -106,6 +102,26 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         else if constexpr (L >= 3) {
           if (r1 == 2) first(std::integral_constant<int, 2>());
           else if constexpr (L >= 4) first(std::integral_constant<int, 3>());
+        }
+      }
+    }
+    // Two workgroup barriers per LDS transpose, both around the WRITE: one before it (every wave has read what the image
+    // held: the previous trip's columns, or the previous transform's) and one after it (the columns are in the image).
+    // A wave's reads are followed by its arithmetic, not by a barrier, so no wave waits at a barrier for LDS latency.
+    if (ntrips > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        const u32 lsi = opaque_copy(lane_step(it));
+        const u32 T = __brev(lsi) >> (32 - (logn - L));
+        if (CTLOGN && r1 == (u32)L) {                              // full first trip: columns T + e TP
+          const u32 aT = M::at(T);
+#pragma unroll
+          for (int e = 0; e < R; ++e) img[M::col(aT, e, cs)] = x[it][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < R; ++e) img[M::at(Ge::pos(logn, (int)r1, T, e))] = x[it][e];
         }
       }
     }
@@ -122,7 +138,6 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
           x[it][e] = v.lo; x[it][e + 1] = v.hi;
         }
       }
-      __syncthreads();                                             // everyone has read: the image may be overwritten
       const bool uniform = (int)logn - (int)s0 - L >= 6;           // the trip's twiddles depend on (lane-step >> 6) only
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -136,24 +151,37 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
             }
           }
         };
-        if (uniform) {
-          const u32 ub = wave_uniform(base0) + zero;
-          cg_trip<E, GROUP, AM, L, false>(x[it], ar,
-            [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (ub >> decltype(j_)::value)]; }, after);
-        } else if (rev) {
-          cg_trip<E, GROUP, AM, L, true>(x[it], ar,
-            [&](auto j_, auto h_) {
-              return ltab[cg_twmap<LAYOUT>((n >> 1) - ((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value)), big)];
-            }, after);
-        } else {
-          cg_trip<E, GROUP, AM, L, false>(x[it], ar,
-            [&](auto j_, auto h_) {
-              return ltab[cg_twmap<LAYOUT>((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value), big)];
-            }, after);
-        }
-        if (trip + 1 < ntrips) {
+        // (par: parity of s0, for the scheduled arithmetic's fold-on-even-stages rule; a compile-time 0 otherwise)
+        auto run = [&](auto par_) {
+          constexpr int PAR = decltype(par_)::value;
+          if (uniform) {
+            const u32 ub = wave_uniform(base0) + zero;
+            cg_trip<E, GROUP, AM, L, false, PAR>(x[it], ar,
+              [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (ub >> decltype(j_)::value)]; }, after);
+          } else if (rev) {
+            cg_trip<E, GROUP, AM, L, true, PAR>(x[it], ar,
+              [&](auto j_, auto h_) {
+                return ltab[cg_twmap<GROUP, LAYOUT>((n >> 1) - ((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value)), big)];
+              }, after);
+          } else {
+            cg_trip<E, GROUP, AM, L, false, PAR>(x[it], ar,
+              [&](auto j_, auto h_) {
+                return ltab[cg_twmap<GROUP, LAYOUT>((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value), big)];
+              }, after);
+          }
+        };
+        if constexpr (AM == CGA_SPLIT_SCHED) {
+          if (s0 & 1u) run(std::integral_constant<int, 1>()); else run(std::integral_constant<int, 0>());
+        } else run(std::integral_constant<int, 0>());
+      }
+      if (trip + 1 < ntrips) {
+        __syncthreads();                                           // every wave has read this trip's input
 #pragma unroll
-          for (int e = 0; e < R; ++e) img[M::at(T + ((u32)e << cs))] = x[it][e];
+        for (int it = 0; it < ITERS; ++it) {
+          if (!is_live(it)) continue;
+          const u32 T = opaque_copy(lane_step(it)), aT = M::at(T);
+#pragma unroll
+          for (int e = 0; e < R; ++e) img[CTLOGN ? M::col(aT, e, cs) : M::at(T + ((u32)e << cs))] = x[it][e];
         }
       }
     }
@@ -163,14 +191,14 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // lane-step is taken through opaque_copy per use so that base + offset is not a loop invariant of the row loop
   // (hoisted, every column's address is a 64-bit VGPR pair that lives across the whole loop: polymul_fused_kernel).
   // raw words of one row: x[it][e] = in[row n + ls + e TP] (unit stride across lanes)
-  auto load_row = [&](E (&x)[ITERS][R], const E* __restrict__ in, u32 row) {
+  auto load_row = [&](E (&x)[ITERS][R], const E* __restrict__ in, u32 row, u32 zero) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
       const u32 tl = opaque_copy(lane_step(it));
 #pragma unroll
       for (int e = 0; e < R; ++e) {
-        const TN_GLOBAL_AS E* cp = uniform_ptr(in + ((size_t)row << logn) + ((u32)e << cs));
+        const TN_GLOBAL_AS E* cp = uniform_ptr(in + ((size_t)row << logn) + ((u32)e << cs) + zero);
 #if TN_CG_NT_STREAM
         x[it][e] = __builtin_nontemporal_load(cp + tl);
 #else
@@ -180,7 +208,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     }
   };
   // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order
-  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], bool twisted) {
+  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], bool twisted, const Tw* tab) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
@@ -188,8 +216,8 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       if (twisted) {
         static_for<0, R>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
-          const TN_GLOBAL_AS Tw* cp = uniform_ptr(psi_pow + ((u32)e << cs));
-          y[it][Ge::brvL(e)] = A::in_mul(x[it][e], *(const Tw*)(cp + tl), ar);      // (generic pointer for the host pass; the access stays global_load)
+          const TN_GLOBAL_AS Tw* cp = uniform_ptr(tab + ((u32)e << cs));
+          y[it][Ge::brvL(e)] = A::in_mul(x[it][e], ld_global(cp + tl), ar);
         });
       } else {
         static_for<0, R>([&](auto e_) { constexpr int e = decltype(e_)::value; y[it][Ge::brvL(e)] = A::in_red(x[it][e], ar); });
@@ -199,7 +227,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // out[row n + ls + e TP] = x[e] * (psi^-(ls + e TP) n^-1)   (kind 2; cg_ntt.py:74-75 and :91-92 in one exact product),
   //                          x[e] * n^-1 (kind 1; :74-75),  canonical x[e] (kind 0)
   const Tw ninv = AM == CGA_SHOUP ? ar.ninv : ar.fninv;            // n^-1 in the record format of the plan's tables
-  auto store_row = [&](const E (&x)[ITERS][R], u32 row, int kind) {
+  auto store_row = [&](const E (&x)[ITERS][R], u32 row, int kind, u32 zero, const Tw* tab) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
@@ -208,8 +236,8 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       if (kind == 2) {
         static_for<0, R>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
-          const TN_GLOBAL_AS Tw* cp = uniform_ptr(psi_inv_ninv + ((u32)e << cs));
-          v[e] = A::out_mul(x[it][e], *(const Tw*)(cp + tl), ar);
+          const TN_GLOBAL_AS Tw* cp = uniform_ptr(tab + ((u32)e << cs));
+          v[e] = A::out_mul(x[it][e], ld_global(cp + tl), ar);
         });
       } else if (kind == 1) {
 #pragma unroll
@@ -220,7 +248,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       }
 #pragma unroll
       for (int e = 0; e < R; ++e) {
-        TN_GLOBAL_AS E* cp = uniform_ptr(out + ((size_t)row << logn) + ((u32)e << cs));
+        TN_GLOBAL_AS E* cp = uniform_ptr(out + ((size_t)row << logn) + ((u32)e << cs) + zero);
 #if TN_CG_NT_STREAM
         __builtin_nontemporal_store(v[e], cp + tl);
 #else
@@ -238,25 +266,28 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // before the last transform of the current row and consumed at the top of the next iteration.
   E xa[ITERS][R], xn[ITERS][R];
   u32 row = blockIdx.x;
-  if (row < batch) load_row(xn, a, row);
+  if (row < batch) load_row(xn, a, row, 0u);
   for (; row < batch; row += gridDim.x) {
     const u32 next = row + gridDim.x;
+    const u32 zero = opaque_zero();                                // pins the column bases (scalar adds) inside the row loop
+    const Tw* tw_in = opaque_sptr(psi_pow);
+    const Tw* tw_out = opaque_sptr(psi_inv_ninv);
     const u32 nrow = next < batch ? next : row;                    // (after the last row this row is read again and dropped: no branch around the prefetch)
     if (!product) {
       E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
-      enter(xa, xn, mode == CG_TWIST_FWD);
-      load_row(xn, a, nrow);
-      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, 1); }       // cg_intt: cg_ntt.py:68-75
-      else { transform(xa, om_fwd, false, tr); store_row(xa, row, 0); }
+      enter(xa, xn, mode == CG_TWIST_FWD, tw_in);
+      load_row(xn, a, nrow, zero);
+      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, 1, zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
+      else { transform(xa, om_fwd, false, tr); store_row(xa, row, 0, zero, tw_out); }
     } else {
       // nwc_poly_mult (cg_ntt.py:78-92); CG_CYCLIC_POLYMUL: the same chain without twist / untwist = python_poly_mult
       // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
       const bool twisted = mode != CG_CYCLIC_POLYMUL;
       E xb[ITERS][R];
-      load_row(xb, b, row);                                        // in flight while a is transformed
-      enter(xa, xn, twisted);                                      // :82
+      load_row(xb, b, row, zero);                                      // in flight while a is transformed
+      enter(xa, xn, twisted, tw_in);                                    // :82
       transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
-      enter(xn, xb, twisted);                                      // :83
+      enter(xn, xb, twisted, tw_in);                                    // :83
       transform(xn, om_fwd, false, nullptr);                       // :87
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -267,10 +298,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
           if constexpr ((e & 1) == 1) sched_fence();               // two products in flight at a time
         });
       }
-      load_row(xn, a, nrow);
+      load_row(xn, a, nrow, zero);
       if (restage) { __syncthreads(); stage_table(om_inv); }       // (the transform's first barrier orders the staging before its first read)
       transform(xb, om_inv, !restage, nullptr);                    // :90 (:72-73)
-      store_row(xb, row, twisted ? 2 : 1);
+      store_row(xb, row, twisted ? 2 : 1, zero, tw_out);
       if (restage) { __syncthreads(); stage_table(om_fwd); }
     }
   }

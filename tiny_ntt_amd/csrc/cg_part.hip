@@ -2,7 +2,7 @@
 // -DTN_CG_PART=k by the Makefile so the slices build in parallel:
 //   0  32-bit lanes, Shoup records                     1  64-bit lanes, Shoup records (canonical plans, omega-only / any-psi plans)
 //   2  64-bit lanes, split records, canonical (traces)  3  64-bit lanes, split records, lazy, any n
-//   4-6  64-bit lanes, split records, lazy, n = 4096 compiled in: GROUP {1, 2} / 4 / 8 x the three LDS layouts (BASELINE config 5)
+//   4-6  64-bit lanes, split records, lazy with the static fold schedule, n = 4096 compiled in: GROUP {1, 2} / 4 / 8 x the three LDS layouts (BASELINE config 5)
 #include "cg_kernel_impl.h"
 
 namespace tn {
@@ -46,9 +46,9 @@ template <int GROUP>
 static hipError_t by_layout(const tn_plan* p, int mode, int layout, const void* a, const void* b, void* out, void* trace, size_t batch,
                             hipStream_t s) {
   switch (layout) {
-    case CG_LINEAR: return launch_cg_t<u64, GROUP, CG_LINEAR, CGA_SPLIT_LAZY, false, 12>(p, mode, a, b, out, trace, batch, s);
-    case CG_PADDED: return launch_cg_t<u64, GROUP, CG_PADDED, CGA_SPLIT_LAZY, false, 12>(p, mode, a, b, out, trace, batch, s);
-    case CG_SWIZZLED: return launch_cg_t<u64, GROUP, CG_SWIZZLED, CGA_SPLIT_LAZY, false, 12>(p, mode, a, b, out, trace, batch, s);
+    case CG_LINEAR: return launch_cg_t<u64, GROUP, CG_LINEAR, CGA_SPLIT_SCHED, false, 12>(p, mode, a, b, out, trace, batch, s);
+    case CG_PADDED: return launch_cg_t<u64, GROUP, CG_PADDED, CGA_SPLIT_SCHED, false, 12>(p, mode, a, b, out, trace, batch, s);
+    case CG_SWIZZLED: return launch_cg_t<u64, GROUP, CG_SWIZZLED, CGA_SPLIT_SCHED, false, 12>(p, mode, a, b, out, trace, batch, s);
     default: return hipErrorInvalidValue;
   }
 }

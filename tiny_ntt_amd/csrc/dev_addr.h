@@ -23,4 +23,24 @@ __device__ __forceinline__ TN_GLOBAL_AS T* uniform_ptr(T* p) {
 #endif
 }
 
+
+// A (wave-uniform) pointer the compiler cannot see through at this point: everything derived from it is computed after this
+// point — used at the top of a persistent row loop on the TABLE pointers, whose per-column bases (table + e * stride) are
+// otherwise hoisted out of the loop, do not fit the scalar registers there and come back through v_readlane.
+template <typename T> __device__ __forceinline__ T* opaque_sptr(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// *p for a pointer in the global address space (the host pass of hipcc cannot copy a struct out of an address-space-qualified
+// lvalue; it never runs this)
+template <typename T> __device__ __forceinline__ T ld_global(const TN_GLOBAL_AS T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  (void)p;
+  return T();
+#endif
+}
+
 }  // namespace tn

@@ -632,7 +632,7 @@ hipError_t launch_cg(const tn_plan* p, int mode, int group, int layout, const vo
   if (!(p->lazy)) return launch_cg_part1(p, mode, group, layout, big, a, b, out, trace, batch, s);
   // lazy 64-bit plan: every table holds split constants.  Per-stage traces need canonical values at every stage.
   if (trace || !p->cg_lazy) return launch_cg_part2(p, mode, group, layout, big, a, b, out, trace, batch, s);
-  if (p->logn != 12) return launch_cg_part3(p, mode, group, layout, big, a, b, out, trace, batch, s);
+  if (p->logn != 12 || !p->cg_sched) return launch_cg_part3(p, mode, group, layout, big, a, b, out, trace, batch, s);
   if (group <= 2) return launch_cg_part4(p, mode, group, layout, big, a, b, out, trace, batch, s);
   if (group == 4) return launch_cg_part5(p, mode, group, layout, big, a, b, out, trace, batch, s);
   return launch_cg_part6(p, mode, group, layout, big, a, b, out, trace, batch, s);

@@ -114,6 +114,14 @@ TN_HD void sched_fence() {
 #endif
 }
 
+// The same for vector-ALU work only: loads (LDS, global) and scalar instructions may still move across, so twiddle reads
+// can be issued ahead of the butterflies that use them while the live temporaries of the arithmetic stay bounded.
+TN_HD void sched_fence_valu() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0x0124);       // SALU | VMEM read | DS read may cross
+#endif
+}
+
 // Value known to be identical in all lanes of a wave: tells the compiler so (v_readfirstlane),
 // which turns loads indexed by it into scalar loads.  Host: identity.
 TN_HD u32 wave_uniform(u32 x) {

@@ -14,7 +14,7 @@ struct tn_plan {
   int num_cus = 256;
   tn::u32 flags = 0;
   int elem_bytes = 8;
-  bool has_fused = false, lazy = false, cg_lazy = false;
+  bool has_fused = false, lazy = false, cg_lazy = false, cg_sched = false;
   bool omega_only = false;   // created by tn_plan_create_omega: no psi, only the constant-geometry transforms
   bool general = false;      // created by tn_plan_create_general: psi / q not validated, tables computed literally (cg_ntt.py:78-92 for ANY psi)
   int k = 0;            // bitlen(q)

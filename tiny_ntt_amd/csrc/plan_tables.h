@@ -12,6 +12,7 @@ struct HostTables {
   int k = 0, elem_bytes = 8;
   bool lazy = false;
   bool cg_lazy = false;      // lazy, 64-bit lanes, and the constant-geometry kernels may run lazy butterflies (h_cg_lazy_ok)
+  bool cg_sched = false;     // ... with the static fold schedule (h_cg_sched_ok; even log2 n only)
   u32 fold_c = 0;
   u64 n_inv = 0, ninv_w1 = 0;
   std::vector<u64> psi_pow, psi_inv_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
@@ -166,6 +167,40 @@ inline bool h_cg_lazy_ok(int k, u64 c) {
   return x.ok;
 }
 
+// Scheduled lazy butterflies of the constant-geometry kernels (CgArith<.., CGA_SPLIT_SCHED>, cg_core.h): odd stages run on the
+// raw left input with 5q, even stages fold it and use 6q.  Exact replay of the two-stage cycle for (k, c), started from the
+// worst stage-1 input (the bare twist product of any word) and iterated to its fixed point.
+inline bool h_cg_sched_ok(int k, u64 c) {
+  typedef unsigned __int128 u128;
+  SplitExact x(k, c);
+  if (!x.ok) return false;
+  u128 b_odd = x.tmax(x.two64);                       // input bound of an odd stage: twist output (folded / pointwise inputs are smaller)
+  const u128 fold_any = x.folded(x.two64);
+  if (fold_any > b_odd) b_odd = fold_any;
+  for (int it = 0; it < 4; ++it) {
+    // odd stage: u raw (< b_odd), v < b_odd
+    const u128 t1 = x.tmax(b_odd), k5 = (u128)5 * x.q;
+    if (k5 + 1 < t1) x.ok = false;
+    x.fits(b_odd - 1 + t1); x.fits(b_odd + k5);
+    const u128 s1 = b_odd + t1 - 1, d1 = b_odd + k5;
+    const u128 b_even = s1 > d1 ? s1 : d1;
+    // even stage: u folded, v < b_even
+    const u128 bu = x.folded(b_even), t2 = x.tmax(b_even), k6 = (u128)6 * x.q;
+    if (k6 + 1 < t2) x.ok = false;
+    x.fits(bu - 1 + t2); x.fits(bu + k6);
+    const u128 s2 = bu + t2 - 1, d2 = bu + k6;
+    const u128 out = s2 > d2 ? s2 : d2;
+    if (out <= b_odd) {
+      // outputs of the last (even) stage: pointwise_lazy's unfolded operand (< 14q), canonicalisation = fold + one subtraction
+      if (b_odd > (u128)14 * (x.q - 1)) x.ok = false;
+      if (x.folded(b_odd) > (u128)2 * x.q) x.ok = false;
+      return x.ok;
+    }
+    b_odd = out;
+  }
+  return false;
+}
+
 // Is the split-constant lazy policy valid for this (n, k, c)?  (false too when no fused kernel is built for n)
 inline bool h_split_sched_ok(u32 logn, int k, u64 c) {
   switch (logn) {
@@ -193,6 +228,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   if (t.lazy && t.elem_bytes == 8 && !h_split_sched_ok(logn, t.k, t.fold_c)) t.lazy = false;   // ... and the butterflies this
   if (!t.lazy) t.fold_c = 0;
   t.cg_lazy = t.lazy && t.elem_bytes == 8 && h_cg_lazy_ok(t.k, t.fold_c);
+  t.cg_sched = t.cg_lazy && (logn & 1) == 0 && h_cg_sched_ok(t.k, t.fold_c);
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72
   t.n_inv = h_powmod(n % q, q - 2, q);                          // :74
