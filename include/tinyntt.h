@@ -31,6 +31,10 @@
  *     scheduler hands a counter slot to one launch at a time and falls back to a fixed stride when its ring is
  *     busy).  *_host calls and tn_time_poly_mult_dev use the plan's staging buffers and events and take a
  *     per-plan lock: concurrent callers are served one after the other.  Distinct plans/devices are independent.
+ *   - Stream capture: *_dev launches may be captured into a hipGraph (hipStreamBeginCapture on the stream handed in) and
+ *     replayed, also beside live launches of the same plan on other streams.  A captured launch never takes a slot of the
+ *     row scheduler (it runs the fixed row stride), so no replay can share scheduler state with a live launch.  Plan
+ *     creation, the *_host entry points and tn_time_poly_mult_dev synchronise and must not be captured.
  */
 #ifndef TINYNTT_H
 #define TINYNTT_H
@@ -86,7 +90,9 @@ typedef struct tn_plan tn_plan;
  * Replaces: module constants N, Q (cg_ntt.py:5-6) + the psi_2n argument of
  * nwc_poly_mult (:78); BENCH_N/BENCH_Q/BENCH_PSI (software_benchmark/CMakeLists.txt:5-7)
  * and the constexpr tables PsiPowers/OmegaPowers/... (benchmark_ntt_60bit.cpp:43-64).
- * Validates n = 2^m (4 <= n <= 8192; fused kernels for 256 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q).
+ * Validates n = 2^m (4 <= n <= 8192; fused kernels for 256 <= n <= 8192), q odd prime < 2^62, psi^n == -1 (mod q):
+ * the preconditions of the throughput kernels.  Parameters it rejects (TN_EBADPARAM) still have a defined result in the
+ * reference: tn_plan_create_general computes it.
  */
 tn_status tn_plan_create(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags);
 /*
@@ -95,9 +101,18 @@ tn_status tn_plan_create(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, in
  * n-th root, nor have a square root psi mod q; the inverse uses modinv(omega_n) = omega_n^(q-2) (:72) and n^-1 (:74).
  * Such a plan offers tn_ntt_forward_* / tn_ntt_inverse_* / tn_ntt_forward_trace_host with the constant-geometry variants
  * (plus tn_pointwise_mul_dev, tn_fill_lcg_dev, tn_checksum_rows_dev); everything that needs psi returns TN_EUNSUPPORTED.
- * q: odd prime < 2^62 (the reference takes any modulus; non-prime moduli are not supported here).
+ * q: ANY modulus in [2, 2^62), prime or not, odd or even — "modinv" is pow(v, q-2, q) exactly as cg_ntt.py:9-10 computes it.
  */
 tn_status tn_plan_create_omega(tn_plan **out, uint32_t n, uint64_t q, uint64_t omega, int device, uint32_t flags);
+/*
+ * Plan that validates NOTHING beyond the sizes: nwc_poly_mult(a, b, psi_2n) (cg_ntt.py:78-92) never checks psi_2n or the
+ * modulus, so it returns a defined list for every psi_2n (roots of unity or not, zero included) and every modulus; this plan
+ * computes that list: tables psi^i, omega = psi^2, pow(omega, q-2, q), pow(n, q-2, q), pow(psi, q-2, q)^i built literally,
+ * constant-geometry kernels with canonical arithmetic (TN_VARIANT_AUTO = TN_VARIANT_CG; TN_VARIANT_FUSED is unsupported).
+ * Offers every entry point except the merged tables of tn_plan_export_table (4, 5).  q in [2, 2^62); 4 <= n <= 8192.
+ * The Python mirror falls back to it when tn_plan_create rejects (q, psi).
+ */
+tn_status tn_plan_create_general(tn_plan **out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags);
 tn_status tn_plan_destroy(tn_plan *plan);
 
 uint32_t tn_plan_n(const tn_plan *plan);
@@ -108,6 +123,7 @@ uint32_t tn_plan_elem_bytes(const tn_plan *plan); /* 4 or 8 */
 int tn_plan_device(const tn_plan *plan);
 int tn_plan_has_fused(const tn_plan *plan);       /* 1 if TN_VARIANT_FUSED is available for this (n, q) */
 int tn_plan_is_lazy(const tn_plan *plan);         /* 1 if the fused kernel runs with lazy reduction */
+int tn_plan_is_general(const tn_plan *plan);      /* 1 for a plan made by tn_plan_create_general */
 
 /*
  * c[r] = a[r] * b[r] in Z_q[x]/(x^n+1) for r < batch.

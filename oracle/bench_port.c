@@ -183,18 +183,46 @@ double tn_port_time_reps(const tn_port_plan *p, int reps, double *fwd_avg_ns, u6
     return avg;
 }
 
+/*
+ * SURVEY.md §8(d) item 3, the all-core figure: `rows` DISJOINT rows of the synthetic batch the GPU gets (global row r =
+ * make_poly(2r+1) x make_poly(2r+2)), generated before the clock starts, multiplied once each per pass.  Returns avg ns per
+ * poly-mult; *xor_checksum = XOR of the rows' checksums of the last pass (row 0 alone reproduces the reference's printed one).
+ */
+double tn_port_time_rows(const tn_port_plan *p, size_t first_row, size_t rows, int passes, u64 *xor_checksum) {
+    const size_t n = p->n;
+    u64 *a = (u64 *)malloc(3 * rows * n * sizeof(u64));
+    if (!a) return -1.0;
+    u64 *b = a + rows * n, *out = a + 2 * rows * n;
+    for (size_t r = 0; r < rows; ++r) {
+        tn_port_make_poly(2 * (first_row + r) + 1, a + r * n, n, p->q);
+        tn_port_make_poly(2 * (first_row + r) + 2, b + r * n, n, p->q);
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < passes; ++k) tn_port_negacyclic_mul_batch(p, a, b, out, rows);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    u64 x = 0;
+    for (size_t r = 0; r < rows; ++r) x ^= tn_port_checksum(out + r * n, n, p->q);
+    if (xor_checksum) *xor_checksum = x;
+    free(a);
+    return ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / ((double)passes * (double)rows);
+}
+
 #ifdef TN_PORT_MAIN
 /* CLI with the reference's key=value output (main :241-248) and exit codes 0/1/2. */
 int main(int argc, char **argv) {
     size_t n = 4096; u64 q = 1152921504606830593ULL, psi = 431606828070683274ULL;
     int reps = 10, check = 0;
+    size_t rows = 0, first_row = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--check")) check = 1;
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) { reps = atoi(argv[++i]); if (reps < 1) reps = 1; }
         else if (!strcmp(argv[i], "--n") && i + 1 < argc) n = strtoull(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "--q") && i + 1 < argc) q = strtoull(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "--psi") && i + 1 < argc) psi = strtoull(argv[++i], NULL, 10);
-        else { fprintf(stderr, "usage: bench_port [--check] [--reps count] [--n N --q Q --psi PSI]\n"); return 2; }
+        else if (!strcmp(argv[i], "--rows") && i + 1 < argc) rows = strtoull(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "--first-row") && i + 1 < argc) first_row = strtoull(argv[++i], NULL, 10);
+        else { fprintf(stderr, "usage: bench_port [--check] [--reps count] [--n N --q Q --psi PSI] [--rows R [--first-row F]]\n"); return 2; }
     }
     tn_port_plan *p = tn_port_plan_create(n, q, psi);
     if (!p) { fprintf(stderr, "bad parameters: psi^n != -1 mod q or n not a power of two\n"); return 2; }
@@ -206,6 +234,15 @@ int main(int argc, char **argv) {
         tn_port_negacyclic_mul_ntt(p, a, b, c);
         if (memcmp(c, r, n * sizeof(u64))) { fprintf(stderr, "correctness check failed\n"); return 1; }
         free(a);
+    }
+    if (rows) {                      /* disjoint rows of the GPU's batch, `reps` passes over them */
+        u64 x;
+        double avg_rows = tn_port_time_rows(p, first_row, rows, reps, &x);
+        if (avg_rows < 0) { fprintf(stderr, "out of memory\n"); return 1; }
+        printf("bench_port\nN=%zu Q=%llu reps=%d rows=%zu first_row=%zu\n", n, (unsigned long long)q, reps, rows, first_row);
+        printf("avg_ns=%.0f\nxor_checksum=%llu\n", avg_rows, (unsigned long long)x);
+        tn_port_plan_destroy(p);
+        return 0;
     }
     double fwd; u64 fc, cs;
     double avg = tn_port_time_reps(p, reps, &fwd, &fc, &cs);

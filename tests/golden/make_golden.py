@@ -249,9 +249,51 @@ def n8192_cases():
     print("n=8192 cases:", sorted(arrays))
 
 
+def general_psi_cases():
+    """nwc_poly_mult(a, b, psi_2n) validates neither psi_2n nor the modulus (cg_ntt.py:78-92): outputs of the reference for
+    psi that are NOT primitive 2n-th roots (a non-root, a root of too low an order, 0, 1), for composite and even moduli
+    (where "modinv" = pow(v, q-2, q) is not an inverse), at n = 256 / 24-bit and n = 4096 / 60-bit and a few small sizes;
+    8-butterfly twin asserted equal.  Also cg_ntt / cg_intt with composite and even moduli (forward needs no inverse at all)."""
+    arrays, meta = {}, []
+    rng = random.Random(31337)
+    q24, q60 = 8380417, 1152921504606830593
+    sets = [(256, q24, [3, pow(1239911, 4, q24), 0, 1, q24 - 1]),                 # non-root, order n/2, 0, 1, -1
+            (4096, q60, [5, pow(431606828070683274, 2, q60)]),                    # non-root, a root of order n (psi^n = +1)
+            (256, 8380416, [3, 1239911]),                                         # even composite modulus
+            (64, 1000001, [10, 7]),                                               # odd composite (101 * 9901)
+            (16, 2 ** 61 - 2, [12345678901234567]),                               # even, needs 64-bit lanes
+            (8, 2, [1]), (4, 6, [5])]                                             # tiny moduli
+    for n, q, psis in sets:
+        set_params(n, q)
+        a = [rng.randrange(q) for _ in range(n)]; b = [rng.randrange(q) for _ in range(n)]
+        for psi in psis:
+            name = f"n{n}_q{q}_psi{psi}"
+            c = ref.nwc_poly_mult(list(a), list(b), psi)
+            assert c == ref8.nwc_poly_mult_8butterfly(list(a), list(b), psi)
+            arrays[name + "_a"], arrays[name + "_b"], arrays[name + "_c"] = u64(a), u64(b), u64(c)
+            meta.append({"name": name, "kind": "poly_mult", "n": n, "q": q, "psi": psi})
+    for n, q, omegas in [(256, 8380416, [3, 7]), (64, 1000001, [10]), (16, 2 ** 61 - 2, [987654321987654321])]:
+        set_params(n, q)
+        x = [rng.randrange(q) for _ in range(n)]
+        for w in omegas:
+            name = f"n{n}_q{q}_w{w}"
+            X = ref.cg_ntt(list(x), w, q)
+            assert X == ref8.cg_ntt_8butterfly(list(x), w, q)
+            arrays[name + "_x"], arrays[name + "_X"] = u64(x), u64(X)
+            arrays[name + "_inv"] = u64(ref.cg_intt(list(X), w, q))               # whatever cg_intt makes of it (no true inverse exists)
+            meta.append({"name": name, "kind": "ntt", "n": n, "q": q, "omega": w})
+    np.savez_compressed(os.path.join(HERE, "golden_general_psi.npz"), **arrays)
+    with open(os.path.join(HERE, "golden_general_psi.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("general psi cases:", len(meta))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "n8192":
         n8192_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "general_psi":
+        general_psi_cases()
         sys.exit(0)
     for tag in PARAMS:
         gen(tag)
@@ -259,3 +301,4 @@ if __name__ == "__main__":
     hex_digests()
     find_psi_outputs()
     general_omega_cases()
+    general_psi_cases()

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, PARAMS, REF_CHECKSUMS
+from conftest import is_prime, GOLDEN, PARAMS, REF_CHECKSUMS
 
 pytestmark = pytest.mark.gpu
 
@@ -223,6 +223,54 @@ def test_omega_only_plans_follow_the_reference_for_any_omega(eng):
         with pytest.raises(eng.TinyNttError):
             call()
     assert int(plan.export_table("omega_pow")[2]) == 9
+
+
+def test_general_plans_follow_the_reference_for_any_psi_and_modulus(eng, oracle):
+    """nwc_poly_mult(a, b, psi_2n) of the reference validates neither psi_2n nor the modulus (cg_ntt.py:78-92): outputs generated
+    by importing it (tests/golden/make_golden.py: general_psi_cases) for non-root psi (0, 1, -1, low-order roots), composite and
+    even moduli, through the mirror modules (which fall back to tn_plan_create_general when tn_plan_create rejects the
+    parameters) and through the batched engine with every lane grouping; cg_ntt / cg_intt with composite moduli."""
+    import json
+    import tiny_ntt_amd.cg_ntt as cg
+    import tiny_ntt_amd.cg_ntt_8butterfly as cg8
+    from conftest import GOLDEN as GOLDEN_DIR
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "golden_general_psi.json")))
+    arrs = np.load(os.path.join(GOLDEN_DIR, "golden_general_psi.npz"))
+    oldN, oldQ = cg.N, cg.Q
+    try:
+        for m in meta:
+            cg.N, cg.Q = m["n"], m["q"]
+            if m["kind"] == "poly_mult":
+                a, b, c = ([int(v) for v in arrs[m["name"] + s]] for s in ("_a", "_b", "_c"))
+                assert cg.nwc_poly_mult(a, b, m["psi"]) == c, m
+                assert cg8.nwc_poly_mult_8butterfly(a, b, m["psi"]) == c, m
+                plan = eng.get_poly_plan(m["n"], m["q"], m["psi"])
+                if pow(m["psi"], m["n"], m["q"]) != m["q"] - 1 or not is_prime(m["q"]):
+                    assert plan.general and not plan.has_fused
+                    # batched, unreduced words, every lane grouping: the oracle (pinned on these very fixtures) as checker
+                    rng = np.random.default_rng(5)
+                    word = 2 ** 32 - 1 if plan.elem_bytes == 4 else 2 ** 64 - 1
+                    A = rng.integers(0, word, (5, m["n"]), dtype=np.uint64, endpoint=True); B = rng.integers(0, m["q"], (5, m["n"]), dtype=np.uint64)
+                    ref = oracle.poly_mult(A, B, m["q"], m["psi"])
+                    for v in ("cg", "cg2", "cg4", "cg8", "cg8_padded", "cg_swizzled"):
+                        assert np.array_equal(plan.poly_mult(A.astype(plan.dtype), B.astype(plan.dtype), variant=v), ref), (m, v)
+                    with pytest.raises(eng.TinyNttError):
+                        plan.poly_mult(A.astype(plan.dtype), B.astype(plan.dtype), variant="fused")
+            else:
+                x, X, inv = ([int(v) for v in arrs[m["name"] + s]] for s in ("_x", "_X", "_inv"))
+                assert cg.cg_ntt(x, m["omega"], m["q"]) == X, m
+                assert cg8.cg_ntt_8butterfly(x, m["omega"], m["q"]) == X, m
+                assert cg.cg_intt(X, m["omega"], m["q"]) == inv, m
+    finally:
+        cg.N, cg.Q = oldN, oldQ
+    # a general plan on VALID parameters gives what the validated plan gives
+    n, q, psi = PARAMS["P256"]
+    g = eng.get_general_plan(n, q, psi)
+    rng = np.random.default_rng(6)
+    A = rng.integers(0, q, (3, n), dtype=np.uint64).astype(g.dtype); B = rng.integers(0, q, (3, n), dtype=np.uint64).astype(g.dtype)
+    assert np.array_equal(g.poly_mult(A, B), eng.get_plan(n, q, psi).poly_mult(A, B))
+    with pytest.raises(eng.TinyNttError):
+        g.export_table("psi_brv")
 
 
 def test_two_host_threads_share_one_plan(eng, oracle):

@@ -521,3 +521,58 @@ def test_wide_parity_fuzz_all_sizes_and_word_lengths():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "gpu_fuzz.py"), "11", "200"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and ", 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+def test_signed_host_values_and_device_bit_patterns(eng, oracle):
+    """Host arrays are VALUES (negative numbers taken mod q like the reference's %, cg_ntt.py:82-83); device tensors are BIT
+    PATTERNS (torch.int64 storage read as unsigned words).  The same 64 bits therefore mean different residues on the two
+    paths, and each equals what the reference computes for that reading (engine.Plan docstring)."""
+    import torch
+    plan = plan_for(eng, "P4096_60")
+    n, q, psi = PARAMS["P4096_60"]
+    rng = np.random.default_rng(11)
+    a_signed = rng.integers(-2 ** 63, 2 ** 63 - 1, (2, n), dtype=np.int64)
+    b = rng.integers(0, q, (2, n), dtype=np.uint64)
+    as_values = np.array([[int(v) % q for v in row] for row in a_signed], dtype=np.uint64)            # Python's %, what the reference does with ints
+    as_patterns = a_signed.view(np.uint64)
+    ref_values = oracle.poly_mult(as_values, b, q, psi)
+    ref_patterns = oracle.poly_mult(as_patterns % np.uint64(q), b, q, psi)
+    assert np.array_equal(plan.poly_mult(a_signed, b), ref_values)                                     # host, signed: values
+    assert np.array_equal(plan.poly_mult(as_patterns, b), ref_patterns)                                # host, unsigned view: patterns
+    dev = plan.poly_mult(torch.from_numpy(a_signed).to("cuda"), plan.to_device(b))                     # device: patterns
+    assert np.array_equal(plan.to_host(dev), ref_patterns)
+    assert not np.array_equal(ref_values, ref_patterns)
+
+
+def test_graph_capture_uses_the_fixed_stride_and_replays_beside_live_launches(eng):
+    """A launch captured into a hipGraph must not take a slot of the dynamic row scheduler (the slot pointer would be baked into
+    the kernel node while the ring keeps advancing, and a later replay could share a counter pair with a live launch: rows
+    skipped).  Captured launches run the fixed stride (plan.h: sched_acquire).  Capture a few launches, run more live launches than
+    the ring has slots (1,024), then replay the graph while a second stream keeps launching: every result must be right."""
+    import torch
+    plan = plan_for(eng, "P4096_60")
+    rows = 6144                                        # long enough for dynamic row scheduling on the live launches
+    a = plan.fill_lcg(rows, 1, 2); b = plan.fill_lcg(rows, 2, 2)
+    a2 = plan.fill_lcg(rows, 7, 2); b2 = plan.fill_lcg(rows, 8, 2)
+    ref = plan.poly_mult(a, b); ref2 = plan.poly_mult(a2, b2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    c = torch.zeros_like(a); c2 = torch.zeros_like(a)
+    with torch.cuda.stream(s1):
+        plan.poly_mult(a, b, out=c, stream=s1)         # warm-up outside the capture (lazy kernel attributes)
+    s1.synchronize()
+    g = torch.cuda.CUDAGraph()
+    c.zero_(); torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s1):
+        for _ in range(3):
+            plan.poly_mult(a, b, out=c, stream=s1)
+    for _ in range(1100):                              # the ring wraps: slots used before the capture are handed out again
+        plan.poly_mult(a2, b2, out=c2, stream=s2)
+    for rep in range(6):
+        c.zero_(); torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            g.replay()
+        for _ in range(8):                             # live, dynamically scheduled launches beside the replay
+            plan.poly_mult(a2, b2, out=c2, stream=s2)
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref) and torch.equal(c2, ref2), rep

@@ -35,7 +35,8 @@ def test_build_id_names_the_sources_the_library_was_built_from():
     build they belong to, so a library older than its sources (or an id older than the kernels) must not go unnoticed."""
     import hashlib
     d = os.path.join(ROOT, "tiny_ntt_amd", "csrc")
-    files = ["kernels.hip", "capi.cpp", "modarith.h", "fused_core.h", "plan.h", "plan_tables.h", "../../include/tinyntt.h"]
+    files = ["kernels.hip", "cg_part.hip", "capi.cpp", "modarith.h", "fused_core.h", "cg_core.h", "cg_kernel_impl.h", "dev_addr.h", "plan.h",
+             "plan_tables.h", "../../include/tinyntt.h"]        # the order of csrc/Makefile: BUILD_ID
     h = hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in files)).hexdigest()[:16]
     assert engine.build_id() == h, "tiny_ntt_amd/lib/libtinyntt.so is stale: run make -C tiny_ntt_amd/csrc"
 

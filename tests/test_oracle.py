@@ -81,3 +81,23 @@ def test_oracle_follows_the_reference_for_any_omega(oracle):
         assert np.array_equal(oracle.cg_ntt(x, m["omega"], m["q"]), X), m
         if m.get("has_inverse"):
             assert np.array_equal(oracle.cg_intt(X, m["omega"], m["q"]), arrs[m["name"] + "_inv"]), m
+
+
+def test_oracle_follows_the_reference_for_any_psi_and_modulus(oracle):
+    """nwc_poly_mult validates neither psi_2n nor the modulus (cg_ntt.py:78-92): the CPU restatement against outputs of the
+    reference for non-root psi, composite and even moduli (tests/golden/make_golden.py: general_psi_cases)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "golden_general_psi.json")))
+    arrs = np.load(os.path.join(GOLDEN, "golden_general_psi.npz"))
+    assert sum(m["kind"] == "poly_mult" for m in meta) >= 14 and sum(m["kind"] == "ntt" for m in meta) >= 4
+    for m in meta:
+        if m["kind"] == "poly_mult":
+            a, b, c = (arrs[m["name"] + s] for s in ("_a", "_b", "_c"))
+            assert np.array_equal(oracle.poly_mult(a[None], b[None], m["q"], m["psi"])[0], c), m
+            assert np.array_equal(oracle.poly_mult(a[None], b[None], m["q"], m["psi"], group=8)[0], c), m
+        else:
+            x, X = arrs[m["name"] + "_x"], arrs[m["name"] + "_X"]
+            assert np.array_equal(oracle.cg_ntt(x, m["omega"], m["q"]), X), m
+            assert np.array_equal(oracle.cg_intt(X, m["omega"], m["q"]), arrs[m["name"] + "_inv"]), m

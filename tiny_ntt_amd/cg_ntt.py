@@ -95,8 +95,11 @@ def nwc_poly_mult(a: List[int], b: List[int], psi_2n: int, _variant=None) -> Lis
     """new_reference/cg_ntt.py:78-92: c = a*b in Z_Q[x]/(x^N + 1)."""
     if len(a) != N or len(b) != N:
         raise ValueError(f"Expected {N} coefficients")
-    plan = engine.get_plan(N, Q, psi_2n, DEVICE)
-    c = plan.poly_mult(_as_words(a, Q, plan.dtype), _as_words(b, Q, plan.dtype), variant=_variant or POLY_VARIANT)
+    plan = engine.get_poly_plan(N, Q, psi_2n, DEVICE)     # any psi_2n, any modulus: the reference validates neither
+    variant = _variant or POLY_VARIANT
+    if plan.general and variant in ("auto", "fused"):
+        variant = VARIANT if VARIANT in engine.CG_VARIANTS else "cg"
+    c = plan.poly_mult(_as_words(a, Q, plan.dtype), _as_words(b, Q, plan.dtype), variant=variant)
     return [int(v) for v in c]
 
 

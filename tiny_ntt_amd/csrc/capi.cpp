@@ -67,8 +67,10 @@ static hipError_t upload_tw(const std::vector<u64>& vals, const HostTables& t, b
   return hipMemcpy(*dptr, r.data(), r.size() * sizeof(Tw32), hipMemcpyHostToDevice);
 }
 
-extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags) {
-  if (!out) return fail(TN_EINVAL, "tn_plan_create: out is NULL");
+// The three plan constructors share everything but the parameter checks and the tables they build.
+enum PlanKind { PLAN_PSI = 0, PLAN_OMEGA = 1, PLAN_GENERAL = 2 };
+static tn_status plan_new(tn_plan** out, PlanKind kind, uint32_t n, uint64_t q, uint64_t root, int device, uint32_t flags, const char* fn) {
+  if (!out) return fail(TN_EINVAL, std::string(fn) + ": out is NULL");
   *out = nullptr;
   u32 logn = 0;
   while (((u32)1 << logn) < n) ++logn;
@@ -76,15 +78,19 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
     char buf[96]; snprintf(buf, sizeof buf, "Expected a power-of-two length >= 4, got %u", n);
     return fail(TN_EBADLEN, buf);
   }
-  if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
-  if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
+  if (kind == PLAN_PSI) {
+    if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
+    if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
+  } else if (q < 2 || q >= ((u64)1 << 62)) {
+    return fail(TN_EBADPARAM, "the modulus must lie in [2, 2^62)");
+  }
   const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
   if (n > 8192u) {
     char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
     return fail(TN_EBADLEN, buf);
   }
-  psi %= q;
-  if (h_powmod(psi, n, q) != q - 1)
+  root %= q;
+  if (kind == PLAN_PSI && h_powmod(root, n, q) != q - 1)
     return fail(TN_EBADPARAM, "psi must satisfy psi^n == -1 mod q (primitive 2n-th root; benchmark_ntt_60bit.cpp:58-59)");
 
   int ndev = 0;
@@ -97,29 +103,29 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
 
   tn_plan* p = new (std::nothrow) tn_plan();
   if (!p) return fail(TN_ENOMEM, "plan allocation failed");
-  const HostTables t = h_build_tables(n, q, psi, !(flags & TN_PLAN_FORCE_CANONICAL));
-  p->n = n; p->logn = logn; p->q = q; p->psi = psi; p->omega = t.omega;
+  const HostTables t = kind == PLAN_PSI ? h_build_tables(n, q, root, !(flags & TN_PLAN_FORCE_CANONICAL))
+                     : kind == PLAN_OMEGA ? h_build_omega_tables(n, q, root) : h_build_general_tables(n, q, root);
+  p->n = n; p->logn = logn; p->q = q; p->psi = kind == PLAN_OMEGA ? 0 : t.psi; p->omega = t.omega;
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
   p->k = t.k; p->lazy = t.lazy; p->cg_lazy = t.cg_lazy; p->cg_sched = t.cg_sched;
+  p->omega_only = kind == PLAN_OMEGA; p->general = kind != PLAN_PSI;       // (no reversal trick without omega^(n/2) == -1)
   if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
-  p->has_fused = fused_supported(logn, elem_bytes);
+  p->has_fused = kind == PLAN_PSI && fused_supported(logn, elem_bytes);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount;
   }
-
+  struct Up { const std::vector<u64>* v; void** d; };
+  const Up ups[] = {{&t.psi_brv, &p->d_psi_brv}, {&t.psi_inv_brv, &p->d_psi_inv_brv}, {&t.omega_pow, &p->d_omega_pow},
+                    {&t.omega_inv_pow, &p->d_omega_inv_pow}, {&t.psi_pow, &p->d_psi_pow}, {&t.psi_inv_ninv, &p->d_psi_inv_ninv},
+                    {&t.psi_inv_pow, &p->d_psi_inv_pow}, {&t.cyc_brv, &p->d_cyc_brv}, {&t.cyc_inv_brv, &p->d_cyc_inv_brv}};
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = upload_tw(t.psi_brv, t, true, &p->d_psi_brv);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_brv, t, true, &p->d_psi_inv_brv);
-  if (e == hipSuccess) e = upload_tw(t.omega_pow, t, true, &p->d_omega_pow);
-  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, true, &p->d_omega_inv_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_pow, t, true, &p->d_psi_pow);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_ninv, t, true, &p->d_psi_inv_ninv);
-  if (e == hipSuccess) e = upload_tw(t.psi_inv_pow, t, true, &p->d_psi_inv_pow);
-  if (e == hipSuccess) e = upload_tw(t.cyc_brv, t, true, &p->d_cyc_brv);
-  if (e == hipSuccess) e = upload_tw(t.cyc_inv_brv, t, true, &p->d_cyc_inv_brv);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_sched, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
-  if (e == hipSuccess) e = hipMemset(p->d_sched, 0, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
+  for (const Up& u : ups)
+    if (e == hipSuccess && !u.v->empty()) e = upload_tw(*u.v, t, true, u.d);      // (record format: h_make_fused_tw — Shoup unless lazy 64-bit)
+  if (kind == PLAN_PSI) {
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_sched, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
+    if (e == hipSuccess) e = hipMemset(p->d_sched, 0, 2 * tn_plan::SCHED_SLOTS * sizeof(u32));
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -128,47 +134,14 @@ extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint6
   return TN_OK;
 }
 
+extern "C" tn_status tn_plan_create(tn_plan** out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags) {
+  return plan_new(out, PLAN_PSI, n, q, psi, device, flags, "tn_plan_create");
+}
 extern "C" tn_status tn_plan_create_omega(tn_plan** out, uint32_t n, uint64_t q, uint64_t omega, int device, uint32_t flags) {
-  if (!out) return fail(TN_EINVAL, "tn_plan_create_omega: out is NULL");
-  *out = nullptr;
-  u32 logn = 0;
-  while (((u32)1 << logn) < n) ++logn;
-  if (n < 4 || ((u32)1 << logn) != n) {
-    char buf[96]; snprintf(buf, sizeof buf, "Expected a power-of-two length >= 4, got %u", n);
-    return fail(TN_EBADLEN, buf);
-  }
-  if (q < 3 || (q & 1) == 0 || q >= ((u64)1 << 62)) return fail(TN_EBADPARAM, "q must be an odd prime below 2^62");
-  if (!h_is_prime(q)) return fail(TN_EBADPARAM, "q must be prime (modinv uses Fermat, cg_ntt.py:9-10)");
-  const int elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
-  if (n > 8192u) {
-    char buf[96]; snprintf(buf, sizeof buf, "n = %u exceeds the supported maximum for %d-byte coefficients", n, elem_bytes);
-    return fail(TN_EBADLEN, buf);
-  }
-  int ndev = 0;
-  hipError_t he = hipGetDeviceCount(&ndev);
-  if (he != hipSuccess || ndev <= 0) return fail(TN_ENODEVICE, "no HIP device visible; libtinyntt has no CPU fallback");
-  if (device < 0 || device >= ndev) return fail(TN_EINVAL, "device index out of range");
-  DeviceGuard guard(device);
-  if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
-  tn_plan* p = new (std::nothrow) tn_plan();
-  if (!p) return fail(TN_ENOMEM, "plan allocation failed");
-  const HostTables t = h_build_omega_tables(n, q, omega);
-  p->n = n; p->logn = logn; p->q = q; p->psi = 0; p->omega = t.omega;
-  p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
-  p->k = t.k; p->lazy = false; p->cg_lazy = false; p->has_fused = false; p->omega_only = true;
-  if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount;
-  }
-  hipError_t e = upload_tw(t.omega_pow, t, false, &p->d_omega_pow);
-  if (e == hipSuccess) e = upload_tw(t.omega_inv_pow, t, false, &p->d_omega_inv_pow);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreate(&p->ev0);
-  if (e == hipSuccess) e = hipEventCreate(&p->ev1);
-  if (e != hipSuccess) { tn_plan_destroy(p); return fail_hip(e, "plan table upload"); }
-  *out = p;
-  return TN_OK;
+  return plan_new(out, PLAN_OMEGA, n, q, omega, device, flags, "tn_plan_create_omega");
+}
+extern "C" tn_status tn_plan_create_general(tn_plan** out, uint32_t n, uint64_t q, uint64_t psi, int device, uint32_t flags) {
+  return plan_new(out, PLAN_GENERAL, n, q, psi, device, flags, "tn_plan_create_general");
 }
 
 extern "C" tn_status tn_plan_destroy(tn_plan* p) {
@@ -199,6 +172,7 @@ extern "C" uint32_t tn_plan_elem_bytes(const tn_plan* p) { return p ? (uint32_t)
 extern "C" int tn_plan_device(const tn_plan* p) { return p ? p->device : -1; }
 extern "C" int tn_plan_has_fused(const tn_plan* p) { return p && p->has_fused; }
 extern "C" int tn_plan_is_lazy(const tn_plan* p) { return p && p->lazy; }
+extern "C" int tn_plan_is_general(const tn_plan* p) { return p && p->general && !p->omega_only; }
 
 static hipStream_t pick_stream(tn_plan* p, void* stream) { return stream ? (hipStream_t)stream : p->stream; }
 
@@ -290,6 +264,7 @@ extern "C" tn_status tn_schoolbook_dev(tn_plan* p, const void* a, const void* b,
 extern "C" tn_status tn_plan_export_table(tn_plan* p, int which, void* host_out) {
   if (!p || !host_out) return fail(TN_EINVAL, "tn_plan_export_table: NULL argument");
   if (p->omega_only && which != 2 && which != 3) return fail(TN_EUNSUPPORTED, "tn_plan_export_table: an omega-only plan has only the omega tables (2, 3)");
+  if (p->general && (which == 4 || which == 5)) return fail(TN_EUNSUPPORTED, "tn_plan_export_table: only plans from tn_plan_create have the merged (bit-reversed) tables");
   const void* tabs[] = {p->d_psi_pow, p->d_psi_inv_ninv, p->d_omega_pow, p->d_omega_inv_pow, p->d_psi_brv, p->d_psi_inv_brv, p->d_psi_inv_pow};
   if (which < 0 || which > 6) return fail(TN_EINVAL, "tn_plan_export_table: unknown table");
   const size_t count = (which == 2 || which == 3) ? p->n / 2 : p->n;

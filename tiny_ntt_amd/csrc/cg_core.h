@@ -23,6 +23,10 @@
 #pragma once
 #include "fused_core.h"
 
+#ifndef TN_CG_FENCE
+#define TN_CG_FENCE 2            // butterflies between two vector-ALU scheduling fences of a stage (0: none)
+#endif
+
 namespace tn {
 
 enum CgLayout { CG_LINEAR = 0, CG_PADDED = 1, CG_SWIZZLED = 2 };
@@ -183,7 +187,7 @@ TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after
       constexpr bool EVEN = ((S0PAR + j + 1) & 1) == 0;                 // stage number s0 + j + 1 (cg_ntt.py:49)
       if constexpr (SWAP) CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
       else CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[g], z[G + g]);
-      if constexpr ((g & 1) == 1 && g + 1 < G) sched_fence_valu();     // two butterflies in flight at a time: bounds the live temporaries
+      if constexpr (TN_CG_FENCE > 0 && ((g + 1) % (TN_CG_FENCE > 0 ? TN_CG_FENCE : 1)) == 0 && g + 1 < G) sched_fence_valu();   // bounds the butterflies in flight (live temporaries)
     });
 #pragma unroll
     for (int e = 0; e < 2 * G; ++e) x[e] = z[e];

@@ -19,6 +19,9 @@
 #define TN_CG_NT_STREAM 1        // 1: non-temporal loads/stores for the streamed operands (keeps L2 for the tables)
 #endif
 
+// every lambda of the kernel body must be inlined: a call would pass the captured register arrays through scratch memory
+#define TN_INL __attribute__((always_inline))
+
 namespace tn {
 
 constexpr int CG_FLAG_RESTAGE = 0x100;   // or-ed into the kernel's mode: omega^(n/2) != -1 (any-psi plans): the inverse transform of a
@@ -50,6 +53,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   typedef CgArith<E, AM> A;
   typedef typename TwOf<E>::type Tw;
   typedef CgPair<E> Pair;
+  typedef typename TwRawOf<E>::type TwRaw;
   constexpr int R = Ge::R, L = Ge::L, ITERS = CgShape<E, GROUP, BIG>::ITERS;
   const u32 logn = CTLOGN ? (u32)CTLOGN : logn_rt;
   const u32 n = 1u << logn, TP = n >> L;                          // TP: lane-steps per polynomial
@@ -62,19 +66,19 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
   E* img = reinterpret_cast<E*>(tn_smem);
   Tw* ltab = reinterpret_cast<Tw*>(img + ((M::span(n) + 3u) & ~3u));
-  auto stage_table = [&](const Tw* __restrict__ src) {            // omega^j (or omega^-j), j <= n/2
+  auto stage_table = [&](const Tw* __restrict__ src) TN_INL {            // omega^j (or omega^-j), j <= n/2
     for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<GROUP, LAYOUT>(j, big)] = src[j];
   };
 
   // lane-step it of this thread: threadIdx.x + it * blockDim.x.  With n compiled in the launcher starts exactly TP / ITERS
   // threads, so every lane-step is live.
-  auto lane_step = [&](int it) -> u32 { return threadIdx.x + (u32)it * (CTLOGN ? (TP / ITERS) : blockDim.x); };
-  auto is_live = [&](int it) -> bool { return CTLOGN ? true : lane_step(it) < TP; };
+  auto lane_step = [&](int it) TN_INL -> u32 { return threadIdx.x + (u32)it * (CTLOGN ? (TP / ITERS) : blockDim.x); };
+  auto is_live = [&](int it) TN_INL -> bool { return CTLOGN ? true : lane_step(it) < TP; };
 
   // x: one lane-step's registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list, cg_ntt.py:39)
   // -> natural order (x[e] = element ls + e TP of the transform).  glob: the table in global memory for the trips whose
   // twiddles are wave-uniform; the LDS table is read directly, or backwards with the outputs swapped (rev).
-  auto transform = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) {
+  auto transform = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) TN_INL {
     // opaque zero / thread index: keep the (loop-invariant) uniform twiddle loads and per-column LDS addresses of a transform
     // inside the persistent row loop instead of in registers across it (see polymul_fused_kernel)
     const u32 zero = opaque_zero();
@@ -83,7 +87,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       if (!is_live(it)) continue;
       const u32 lsi = opaque_copy(lane_step(it));
       const u32 T = logn > (u32)L ? __brev(lsi) >> (32 - (logn - L)) : 0u;      // first trip: thread t plays lane-step brv(t) (cg_core.h)
-      auto first = [&](auto nst_) {
+      auto first = [&](auto nst_) TN_INL {
         constexpr int NST = decltype(nst_)::value;
         cg_trip<E, GROUP, AM, NST, false>(x[it], ar,
           [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + zero]; },
@@ -143,7 +147,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       for (int it = 0; it < ITERS; ++it) {
         if (!is_live(it)) continue;
         const u32 T = opaque_copy(lane_step(it)), base0 = cg_tw_base0<GROUP>(logn, s0, T);
-        auto after = [&](auto j_) {
+        auto after = [&](auto j_) TN_INL {
           if constexpr (AM != CGA_SPLIT_LAZY) {
             if (tr) {
 #pragma unroll
@@ -152,7 +156,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
           }
         };
         // (par: parity of s0, for the scheduled arithmetic's fold-on-even-stages rule; a compile-time 0 otherwise)
-        auto run = [&](auto par_) {
+        auto run = [&](auto par_) TN_INL {
           constexpr int PAR = decltype(par_)::value;
           if (uniform) {
             const u32 ub = wave_uniform(base0) + zero;
@@ -191,7 +195,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // lane-step is taken through opaque_copy per use so that base + offset is not a loop invariant of the row loop
   // (hoisted, every column's address is a 64-bit VGPR pair that lives across the whole loop: polymul_fused_kernel).
   // raw words of one row: x[it][e] = in[row n + ls + e TP] (unit stride across lanes)
-  auto load_row = [&](E (&x)[ITERS][R], const E* __restrict__ in, u32 row, u32 zero) {
+  auto load_row = [&](E (&x)[ITERS][R], const E* __restrict__ in, u32 row, u32 zero) TN_INL {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
@@ -207,39 +211,49 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       }
     }
   };
-  // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order
-  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], bool twisted, const Tw* tab) {
+  // the lane-step's records of a per-coefficient table: rec[e] = tab[ls + e TP]  (requested; consumed by enter / store_row)
+  auto fetch_records = [&](TwRaw (&rec)[ITERS][R], const Tw* tab) TN_INL {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
       const u32 tl = opaque_copy(lane_step(it));
-      if (twisted) {
-        static_for<0, R>([&](auto e_) {
-          constexpr int e = decltype(e_)::value;
-          const TN_GLOBAL_AS Tw* cp = uniform_ptr(tab + ((u32)e << cs));
-          y[it][Ge::brvL(e)] = A::in_mul(x[it][e], ld_global(cp + tl), ar);
-        });
-      } else {
-        static_for<0, R>([&](auto e_) { constexpr int e = decltype(e_)::value; y[it][Ge::brvL(e)] = A::in_red(x[it][e], ar); });
-      }
+      static_for<0, R>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        rec[it][e] = ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(tab + ((u32)e << cs)) + tl));
+      });
+    }
+  };
+  // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order
+  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], auto twisted_, const Tw* tab) TN_INL {
+    constexpr bool TWISTED = decltype(twisted_)::value;
+    TwRaw rec[ITERS][R];
+    if constexpr (TWISTED) fetch_records(rec, tab);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      static_for<0, R>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr (TWISTED) y[it][Ge::brvL(e)] = A::in_mul(x[it][e], tw_pack(rec[it][e]), ar);
+        else y[it][Ge::brvL(e)] = A::in_red(x[it][e], ar);
+      });
     }
   };
   // out[row n + ls + e TP] = x[e] * (psi^-(ls + e TP) n^-1)   (kind 2; cg_ntt.py:74-75 and :91-92 in one exact product),
   //                          x[e] * n^-1 (kind 1; :74-75),  canonical x[e] (kind 0)
   const Tw ninv = AM == CGA_SHOUP ? ar.ninv : ar.fninv;            // n^-1 in the record format of the plan's tables
-  auto store_row = [&](const E (&x)[ITERS][R], u32 row, int kind, u32 zero, const Tw* tab) {
+  auto store_row = [&](const E (&x)[ITERS][R], u32 row, auto kind_, u32 zero, const Tw* tab) TN_INL {
+    constexpr int KIND = decltype(kind_)::value;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
       const u32 tl = opaque_copy(lane_step(it));
       E v[R];
-      if (kind == 2) {
+      if constexpr (KIND == 2) {
         static_for<0, R>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
-          const TN_GLOBAL_AS Tw* cp = uniform_ptr(tab + ((u32)e << cs));
-          v[e] = A::out_mul(x[it][e], ld_global(cp + tl), ar);
+          v[e] = A::out_mul(x[it][e], tw_pack(ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(tab + ((u32)e << cs)) + tl))), ar);
         });
-      } else if (kind == 1) {
+      } else if constexpr (KIND == 1) {
 #pragma unroll
         for (int e = 0; e < R; ++e) v[e] = A::out_mul(x[it][e], ninv, ar);
       } else {
@@ -258,51 +272,67 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     }
   };
 
-  const bool product = mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL;
   stage_table(mode == CG_NTT_INV ? om_inv : om_fwd);
   __syncthreads();
 
+  typedef std::integral_constant<bool, true> True;
+  typedef std::integral_constant<bool, false> False;
+  typedef std::integral_constant<int, 0> K0;
+  typedef std::integral_constant<int, 1> K1;
+  typedef std::integral_constant<int, 2> K2;
   // Persistent workgroup over rows blockIdx.x, + gridDim.x, ...; the next row's first operand is requested from HBM
-  // before the last transform of the current row and consumed at the top of the next iteration.
+  // before the last transform of the current row and consumed at the top of the next iteration.  One body per mode,
+  // each with its switches compiled in (a run-time switch inside a body keeps both sides' registers alive).
   E xa[ITERS][R], xn[ITERS][R];
   u32 row = blockIdx.x;
   if (row < batch) load_row(xn, a, row, 0u);
+  // nwc_poly_mult (cg_ntt.py:78-92); untwisted: the same chain without twist / untwist = python_poly_mult
+  // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
+  auto product_row = [&](auto twisted_, u32 nrow, u32 zero, const Tw* tw_in, const Tw* tw_out) TN_INL {
+    constexpr bool TWISTED = decltype(twisted_)::value;
+    E xb[ITERS][R];
+    // vector-memory operations retire in order: b's row (HBM) is requested AFTER the twist of a has consumed its records
+    // (L2), so that nothing of a's path waits for HBM; b stays in flight while a is transformed
+    enter(xa, xn, twisted_, tw_in);                                // :82
+    sched_fence();
+    load_row(xb, b, row, zero);
+    sched_fence();
+    transform(xa, om_fwd, false, nullptr);                         // :86  A^ stays in registers
+    sched_fence();                                                 // (or the scheduler requests b's twist records a whole transform early)
+    enter(xn, xb, twisted_, tw_in);                                // :83
+    transform(xn, om_fwd, false, nullptr);                         // :87
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      static_for<0, R>([&](auto e_) {                              // :88, left in the inverse's first-trip order (bit_reverse_list of :73)
+        constexpr int e = decltype(e_)::value;
+        xb[it][Ge::brvL(e)] = A::pointwise(xa[it][e], xn[it][e], ar);
+        if constexpr ((e & 1) == 1) sched_fence();                 // two products in flight at a time
+      });
+    }
+    load_row(xn, a, nrow, zero);
+    if (restage) { __syncthreads(); stage_table(om_inv); }         // (the transform's first barrier orders the staging before its first read)
+    transform(xb, om_inv, !restage, nullptr);                      // :90 (:72-73)
+    sched_fence();
+    if constexpr (TWISTED) store_row(xb, row, K2(), zero, tw_out);  // :74-75 and :91-92 in one exact product
+    else store_row(xb, row, K1(), zero, tw_out);
+    if (restage) { __syncthreads(); stage_table(om_fwd); }
+  };
   for (; row < batch; row += gridDim.x) {
     const u32 next = row + gridDim.x;
     const u32 zero = opaque_zero();                                // pins the column bases (scalar adds) inside the row loop
     const Tw* tw_in = opaque_sptr(psi_pow);
     const Tw* tw_out = opaque_sptr(psi_inv_ninv);
     const u32 nrow = next < batch ? next : row;                    // (after the last row this row is read again and dropped: no branch around the prefetch)
-    if (!product) {
+    if (mode == CG_POLYMUL) product_row(True(), nrow, zero, tw_in, tw_out);
+    else if (mode == CG_CYCLIC_POLYMUL) product_row(False(), nrow, zero, tw_in, tw_out);
+    else {
       E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
-      enter(xa, xn, mode == CG_TWIST_FWD, tw_in);
+      if (mode == CG_TWIST_FWD) enter(xa, xn, True(), tw_in); else enter(xa, xn, False(), tw_in);
+      sched_fence();
       load_row(xn, a, nrow, zero);
-      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, 1, zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
-      else { transform(xa, om_fwd, false, tr); store_row(xa, row, 0, zero, tw_out); }
-    } else {
-      // nwc_poly_mult (cg_ntt.py:78-92); CG_CYCLIC_POLYMUL: the same chain without twist / untwist = python_poly_mult
-      // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
-      const bool twisted = mode != CG_CYCLIC_POLYMUL;
-      E xb[ITERS][R];
-      load_row(xb, b, row, zero);                                      // in flight while a is transformed
-      enter(xa, xn, twisted, tw_in);                                    // :82
-      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
-      enter(xn, xb, twisted, tw_in);                                    // :83
-      transform(xn, om_fwd, false, nullptr);                       // :87
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        if (!is_live(it)) continue;
-        static_for<0, R>([&](auto e_) {                            // :88, left in the inverse's first-trip order (bit_reverse_list of :73)
-          constexpr int e = decltype(e_)::value;
-          xb[it][Ge::brvL(e)] = A::pointwise(xa[it][e], xn[it][e], ar);
-          if constexpr ((e & 1) == 1) sched_fence();               // two products in flight at a time
-        });
-      }
-      load_row(xn, a, nrow, zero);
-      if (restage) { __syncthreads(); stage_table(om_inv); }       // (the transform's first barrier orders the staging before its first read)
-      transform(xb, om_inv, !restage, nullptr);                    // :90 (:72-73)
-      store_row(xb, row, twisted ? 2 : 1, zero, tw_out);
-      if (restage) { __syncthreads(); stage_table(om_fwd); }
+      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, K1(), zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
+      else { transform(xa, om_fwd, false, tr); store_row(xa, row, K0(), zero, tw_out); }
     }
   }
 }

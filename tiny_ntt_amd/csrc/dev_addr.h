@@ -32,6 +32,16 @@ template <typename T> __device__ __forceinline__ T* opaque_sptr(T* p) {
   return p;
 }
 
+// A twiddle record as a plain vector value (one 16- / 8-byte global load; arrays of these stay in registers, arrays of the record
+// structs did not) and back
+typedef u64 tn_u64x2 __attribute__((ext_vector_type(2)));
+typedef u32 tn_u32x2 __attribute__((ext_vector_type(2)));
+template <typename E> struct TwRawOf;
+template <> struct TwRawOf<u64> { typedef tn_u64x2 type; };
+template <> struct TwRawOf<u32> { typedef tn_u32x2 type; };
+__device__ __forceinline__ Tw64 tw_pack(tn_u64x2 v) { Tw64 t; t.w = v.x; t.wp = v.y; return t; }
+__device__ __forceinline__ Tw32 tw_pack(tn_u32x2 v) { Tw32 t; t.w = v.x; t.wp = v.y; return t; }
+
 // *p for a pointer in the global address space (the host pass of hipcc cannot copy a struct out of an address-space-qualified
 // lvalue; it never runs this)
 template <typename T> __device__ __forceinline__ T ld_global(const TN_GLOBAL_AS T* p) {

@@ -257,9 +257,10 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   return t;
 }
 
-// Tables of an OMEGA-ONLY plan: cg_ntt(a, omega_n, modulus) / cg_intt for ANY omega_n (cg_ntt.py:29-75 only evaluates
-// the butterflies with pow(omega_n, k (i // k), modulus); the inverse uses modinv(omega_n) = omega_n^(q-2), :72, whatever
-// omega_n is).  No psi: only the constant-geometry transforms exist for such a plan.  Canonical policy (Shoup records).
+// Tables of an OMEGA-ONLY plan: cg_ntt(a, omega_n, modulus) / cg_intt for ANY omega_n and any modulus >= 2 (cg_ntt.py:29-75
+// only evaluates the butterflies with pow(omega_n, k (i // k), modulus); the inverse uses modinv(omega_n) = omega_n^(q-2), :72,
+// and n^(q-2), :74, whatever omega_n and the modulus are).  No psi: only the constant-geometry transforms exist for such a
+// plan.  Canonical policy (Shoup records).
 inline HostTables h_build_omega_tables(u32 n, u64 q, u64 omega) {
   HostTables t;
   u32 logn = 0;
@@ -271,6 +272,33 @@ inline HostTables h_build_omega_tables(u32 n, u64 q, u64 omega) {
   t.lazy = false; t.cg_lazy = false; t.fold_c = 0;
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);             // modinv(omega_n): cg_ntt.py:9-10, :72
   t.n_inv = h_powmod(n % q, q - 2, q);                           // :74
+  t.omega_pow.resize(n / 2 + 1); t.omega_inv_pow.resize(n / 2 + 1);
+  u64 w = 1 % q, wi = 1 % q;
+  for (u32 j = 0; j <= n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }
+  t.ninv_w1 = t.n_inv;
+  return t;
+}
+
+// Tables of a GENERAL plan: nwc_poly_mult(a, b, psi_2n) for ANY psi_2n and any modulus >= 2, computed literally as
+// cg_ntt.py:78-92 does — psi^i (:82-83), omega = psi^2 (:85), "modinv" = pow(v, q-2, q) whether or not that is an inverse
+// (:9-10, :72, :74, :91), psi_inv^i (:92).  Nothing is validated; canonical policy (Shoup records); constant-geometry kernels only.
+inline HostTables h_build_general_tables(u32 n, u64 q, u64 psi) {
+  HostTables t;
+  u32 logn = 0;
+  while (((u32)1 << logn) < n) ++logn;
+  t.n = n; t.logn = logn; t.q = q; t.psi = psi % q; t.omega = h_mulmod(t.psi, t.psi, q);
+  t.elem_bytes = q < ((u64)1 << 31) ? 4 : 8;
+  t.k = h_bitlen(q);
+  t.mu = (u64)((((unsigned __int128)1) << (2 * t.k)) / q);
+  t.lazy = false; t.cg_lazy = false; t.cg_sched = false; t.fold_c = 0;
+  const u64 psi_inv = h_powmod(t.psi, q - 2, q), omega_inv = h_powmod(t.omega, q - 2, q);
+  t.n_inv = h_powmod(n % q, q - 2, q);
+  t.psi_pow.resize(n); t.psi_inv_pow.resize(n); t.psi_inv_ninv.resize(n);
+  u64 f = 1 % q, g = 1 % q;
+  for (u32 i = 0; i < n; ++i) {
+    t.psi_pow[i] = f; t.psi_inv_pow[i] = g; t.psi_inv_ninv[i] = h_mulmod(g, t.n_inv, q);
+    f = h_mulmod(f, t.psi, q); g = h_mulmod(g, psi_inv, q);
+  }
   t.omega_pow.resize(n / 2 + 1); t.omega_inv_pow.resize(n / 2 + 1);
   u64 w = 1 % q, wi = 1 % q;
   for (u32 j = 0; j <= n / 2; ++j) { t.omega_pow[j] = w; t.omega_inv_pow[j] = wi; w = h_mulmod(w, t.omega, q); wi = h_mulmod(wi, omega_inv, q); }

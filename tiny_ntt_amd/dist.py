@@ -100,3 +100,15 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_floats(values, device=None):
+    """Every rank's list of floats, in rank order, on every rank (bench.py: per-rank rows and kernel times)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [list(map(float, values))]
+    t = torch.tensor(list(map(float, values)), dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.tolist()] for o in out]

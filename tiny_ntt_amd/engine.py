@@ -34,7 +34,7 @@ PLAN_FORCE_CANONICAL = 1
 
 # Every symbol include/tinyntt.h declares (tests check the built library exports them all).
 EXPORTED_SYMBOLS = (
-    "tn_plan_create", "tn_plan_create_omega", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
+    "tn_plan_create", "tn_plan_create_omega", "tn_plan_create_general", "tn_plan_is_general", "tn_plan_destroy", "tn_plan_n", "tn_plan_q", "tn_plan_psi", "tn_plan_omega",
     "tn_plan_elem_bytes", "tn_plan_device", "tn_plan_has_fused", "tn_plan_is_lazy",
     "tn_poly_mult_dev", "tn_poly_mult_host", "tn_plan_set_host_chunk_rows", "tn_cyclic_poly_mult_dev", "tn_pointwise_mul_dev", "tn_schoolbook_dev",
     "tn_plan_export_table", "tn_ntt_forward_dev", "tn_ntt_inverse_dev",
@@ -75,9 +75,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     vp, u32, u64, sz, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
     lib.tn_plan_create.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ci, u32]
     lib.tn_plan_create_omega.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ci, u32]
+    lib.tn_plan_create_general.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ci, u32]
     lib.tn_plan_destroy.argtypes = [vp]
     for name, res in (("tn_plan_n", u32), ("tn_plan_q", u64), ("tn_plan_psi", u64), ("tn_plan_omega", u64),
-                      ("tn_plan_elem_bytes", u32), ("tn_plan_device", ci), ("tn_plan_has_fused", ci), ("tn_plan_is_lazy", ci)):
+                      ("tn_plan_elem_bytes", u32), ("tn_plan_device", ci), ("tn_plan_has_fused", ci), ("tn_plan_is_lazy", ci),
+                      ("tn_plan_is_general", ci)):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = res
     lib.tn_poly_mult_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
@@ -139,10 +141,21 @@ class Plan:
     Replaces the reference's module constants N, Q (cg_ntt.py:5-6), the psi_2n
     argument (:78) and the constexpr tables of the C++ benchmark
     (benchmark_ntt_60bit.cpp:43-64).
+
+    How coefficients are read (the reference takes Python ints and reduces them with %, cg_ntt.py:82-83):
+      * HOST arrays / lists are VALUES: Python ints of any size and sign, and numpy signed integers, are taken mod q with
+        Python's non-negative % (-1 -> q - 1); unsigned words wider than the plan's lanes are reduced, not truncated;
+        floats raise TypeError.  So a numpy int64 array that was meant as a bag of 64-bit PATTERNS (words >= 2^63 showing as
+        negatives, e.g. tensor.numpy() of a torch int64 tensor) must be passed as .view(np.uint64).
+      * DEVICE tensors are BIT PATTERNS: torch has no unsigned 64-bit dtype, so torch.int64 / int32 storage is read as
+        unsigned words (torch_dtype); the kernels take every word mod q.
+    tests/test_host_logic.py::test_host_rows_take_integers_mod_q_and_refuse_floats and
+    tests/test_gpu_parity.py::test_signed_host_values_and_device_bit_patterns pin both rules against the reference's %.
     """
 
-    def __init__(self, n: int, q: int, psi: int, device: int = 0, flags: int = 0, omega: int = None):
-        """omega given (psi ignored): an OMEGA-ONLY plan (tn_plan_create_omega) — cg_ntt / cg_intt for any omega_n."""
+    def __init__(self, n: int, q: int, psi: int, device: int = 0, flags: int = 0, omega: int = None, general: bool = False):
+        """omega given (psi ignored): an OMEGA-ONLY plan (tn_plan_create_omega) — cg_ntt / cg_intt for any omega_n.
+        general: tn_plan_create_general — nothing validated, nwc_poly_mult for ANY psi / modulus as cg_ntt.py:78-92 computes it."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         if not (0 <= int(n) < 2 ** 32):
@@ -150,7 +163,10 @@ class Plan:
         if not (0 < int(q) < 2 ** 64):
             raise TinyNttError(TN_EBADPARAM, "q must be an odd prime below 2^62")
         self.omega_only = omega is not None
-        if self.omega_only:
+        self.general = bool(general) and not self.omega_only
+        if self.general:
+            _check(self._lib, self._lib.tn_plan_create_general(ctypes.byref(self._h), int(n), int(q), int(psi) % int(q), int(device), int(flags)))
+        elif self.omega_only:
             _check(self._lib, self._lib.tn_plan_create_omega(ctypes.byref(self._h), int(n), int(q), int(omega) % int(q), int(device), int(flags)))
             psi = 0
         else:
@@ -179,7 +195,7 @@ class Plan:
     @property
     def torch_dtype(self):
         import torch
-        return torch.int32 if self.elem_bytes == 4 else torch.int64   # bit patterns are unsigned
+        return torch.int32 if self.elem_bytes == 4 else torch.int64   # DEVICE tensors: bit patterns, read as unsigned words (class docstring)
 
     def _host_rows(self, x, name):
         arr = np.asarray(x)
@@ -404,6 +420,26 @@ def get_omega_plan(n: int, q: int, omega: int, device: int = 0) -> Plan:
     if p is None:
         p = _plan_cache[key] = Plan(int(n), int(q), 0, int(device), 0, omega=int(omega))
     return p
+
+
+def get_general_plan(n: int, q: int, psi: int, device: int = 0) -> Plan:
+    """Cached general plan (tn_plan_create_general): nwc_poly_mult for any psi_2n / modulus, as cg_ntt.py:78-92 computes it."""
+    key = ("general", int(n), int(q), int(psi) % int(q), int(device))
+    p = _plan_cache.get(key)
+    if p is None:
+        p = _plan_cache[key] = Plan(int(n), int(q), int(psi), int(device), 0, general=True)
+    return p
+
+
+def get_poly_plan(n: int, q: int, psi: int, device: int = 0) -> Plan:
+    """The plan the reference-shaped entry points use: the validated one (throughput kernels) when (q, psi) admit it,
+    else the general one — the reference validates neither (cg_ntt.py:78-92)."""
+    try:
+        return get_plan(n, q, psi, device)
+    except TinyNttError as e:
+        if e.status != TN_EBADPARAM:
+            raise
+    return get_general_plan(n, q, psi, device)
 
 
 def clear_plan_cache():

@@ -1,9 +1,13 @@
 #!/bin/bash
 # Time every BASELINE shape for several library variants: tools/gpu_ab_all.sh name1 name2 ...  ("base" = libtinyntt.so)
+# Each step runs through `tos` (gpu_lib.sh) as a plain command writing to a file, never on the left of a pipeline: a step that
+# hits its limit ends the whole call (exit 9) instead of only its pipeline subshell.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 . "$R/tools/gpu_lib.sh"
+OUT=$R/gpurun_out/ab; mkdir -p $OUT
+lib_of() { if [ "$1" = base ]; then echo $R/tiny_ntt_amd/lib/libtinyntt.so; else echo $R/tiny_ntt_amd/lib/libtinyntt_$1.so; fi; }
 for n in "$@"; do
-  if [ "$n" = base ]; then L=$R/tiny_ntt_amd/lib/libtinyntt.so; else L=$R/tiny_ntt_amd/lib/libtinyntt_$n.so; fi
   echo "== $n"
-  TINYNTT_LIB=$L tos 200 python $R/tools/gpu_configs.py 2>&1 | grep -E "batch|fused"
+  TINYNTT_LIB=$(lib_of $n) tos 200 python $R/tools/gpu_configs.py > $OUT/aball_$n.txt 2>&1
+  grep -E "batch|fused" $OUT/aball_$n.txt
 done
