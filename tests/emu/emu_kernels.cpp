@@ -229,7 +229,7 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
   auto table = [&](const std::vector<u64>& v) { return split ? h_fused_table<E>(v, t) : h_tw_table<E>(v, t.q); };
   const std::vector<Tw> fwd = table(t.omega_pow), inv = table(t.omega_inv_pow), psi_pow = table(t.psi_pow), psi_inv_ninv = table(t.psi_inv_ninv);
   const Tw ninv = split ? ar.fninv : ar.ninv;
-  const bool big = n >= 512;
+  const bool big = n >= 512 && TP >= 256;
   std::vector<E> img(M::span(n) + 4, (E)0xDEADBEEFu);
   std::vector<Tw> ldstab(n / 2 + 1);
   auto stage_table = [&](const std::vector<Tw>& g) { for (u32 j = 0; j <= n / 2; ++j) ldstab[cg_twmap<GROUP, LAYOUT>(j, big)] = g[j]; };

@@ -45,8 +45,8 @@ template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
 __global__ void __launch_bounds__((CgShape<E, GROUP, BIG>::THREADS_MAX), (CgShape<E, GROUP, BIG>::MIN_WAVES))
 cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>::type* __restrict__ om_fwd,
           const typename TwOf<E>::type* __restrict__ om_inv, const typename TwOf<E>::type* __restrict__ psi_pow,
-          const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const E* __restrict__ a, const E* __restrict__ b,
-          E* __restrict__ out, E* __restrict__ trace, u32 batch) {
+          const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const typename TwOf<E>::type* __restrict__ psi_inv_pow,
+          const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* __restrict__ trace, u32 batch) {
   // (the tables are separate __restrict__ arguments so that wave-uniform twiddle loads become scalar loads: see polymul_fused_kernel)
   typedef CgGeom<GROUP> Ge;
   typedef CgMap<E, GROUP, LAYOUT> M;
@@ -59,7 +59,8 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   const u32 n = 1u << logn, TP = n >> L;                          // TP: lane-steps per polynomial
   const u32 cs = logn - L;                                        // log2 TP: column e of a lane-step starts at e << cs
   const u32 ntrips = Ge::ntrips(logn), r1 = Ge::first_stages(logn);
-  const bool big = n >= 512;                                      // the table swizzle maps record n/2 to itself from there on
+  const bool big = n >= 512 && TP >= 256;                         // the table swizzle permutes inside aligned 256-record blocks: it maps record n/2 to
+                                                                  // itself and commutes with the per-stage block offsets h (n >> (j+1)) >= TP from there on
   const int mode = mode_flags & 0xff;
   const bool restage = (mode_flags & CG_FLAG_RESTAGE) != 0;
 
@@ -74,6 +75,19 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // threads, so every lane-step is live.
   auto lane_step = [&](int it) TN_INL -> u32 { return threadIdx.x + (u32)it * (CTLOGN ? (TP / ITERS) : blockDim.x); };
   auto is_live = [&](int it) TN_INL -> bool { return CTLOGN ? true : lane_step(it) < TP; };
+
+#ifdef TN_CG_STAMPS
+  // DIAGNOSTIC BUILD ONLY (tools/gpu_cg_stamps.py): per-wave cycle counts (s_memtime) of the phases of a product row and of
+  // the time spent waiting at workgroup barriers, accumulated in scalar registers and written once, at the end, to a
+  // buffer of their own (the trace pointer, unused by products); no output value depends on them.
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_bar = 0, st_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = st_last;
+#define TN_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#define TN_BARRIER() do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); st_bar += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define TN_STAMP(k) do { } while (0)
+#define TN_BARRIER() __syncthreads()
+#endif
 
   // x: one lane-step's registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list, cg_ntt.py:39)
   // -> natural order (x[e] = element ls + e TP of the transform).  glob: the table in global memory for the trips whose
@@ -113,7 +127,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     // held: the previous trip's columns, or the previous transform's) and one after it (the columns are in the image).
     // A wave's reads are followed by its arithmetic, not by a barrier, so no wave waits at a barrier for LDS latency.
     if (ntrips > 1) {
-      __syncthreads();
+      TN_BARRIER();
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         if (!is_live(it)) continue;
@@ -131,7 +145,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     }
     u32 s0 = r1;
     for (u32 trip = 1; trip < ntrips; ++trip, s0 += L) {
-      __syncthreads();                                             // the columns are in the image
+      TN_BARRIER();                                             // the columns are in the image
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         if (!is_live(it)) continue;
@@ -165,12 +179,18 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
           } else if (rev) {
             cg_trip<E, GROUP, AM, L, true, PAR>(x[it], ar,
               [&](auto j_, auto h_) {
-                return ltab[cg_twmap<GROUP, LAYOUT>((n >> 1) - ((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value)), big)];
+                // record n/2 - (h BIG + lo), BIG = n >> (j+1), lo = base0 >> j < BIG  =  (n/2 - (h+1) BIG) + (BIG - lo): the table map
+                // permutes inside aligned 256-record blocks and BIG is a multiple of 256 (or the map is the identity), so it
+                // applies to the lane-dependent part alone and the rest is an immediate offset
+                constexpr int j = decltype(j_)::value;
+                const u32 blk = n >> (j + 1);
+                return ltab[((n >> 1) - ((u32)decltype(h_)::value + 1u) * blk) + cg_twmap<GROUP, LAYOUT>(blk - (base0 >> j), big)];
               }, after);
           } else {
             cg_trip<E, GROUP, AM, L, false, PAR>(x[it], ar,
               [&](auto j_, auto h_) {
-                return ltab[cg_twmap<GROUP, LAYOUT>((u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + (base0 >> decltype(j_)::value), big)];
+                constexpr int j = decltype(j_)::value;
+                return ltab[(u32)decltype(h_)::value * (n >> (j + 1)) + cg_twmap<GROUP, LAYOUT>(base0 >> j, big)];
               }, after);
           }
         };
@@ -179,7 +199,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         } else run(std::integral_constant<int, 0>());
       }
       if (trip + 1 < ntrips) {
-        __syncthreads();                                           // every wave has read this trip's input
+        TN_BARRIER();                                           // every wave has read this trip's input
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           if (!is_live(it)) continue;
@@ -219,7 +239,11 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       const u32 tl = opaque_copy(lane_step(it));
       static_for<0, R>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
+#if defined(TN_CG_ABL_NOREC)          // timing ablation (wrong results): no per-coefficient table loads
+        rec[it][e] = TwRaw{(decltype(TwRaw().x))(ar.fninv.w + e), (decltype(TwRaw().x))ar.fninv.wp};
+#else
         rec[it][e] = ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(tab + ((u32)e << cs)) + tl));
+#endif
       });
     }
   };
@@ -238,38 +262,92 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       });
     }
   };
+  // the same for both operands of a product on ONE fetch of the twist records (both rows already in registers)
+  auto enter2 = [&](E (&ya)[ITERS][R], const E (&xa_)[ITERS][R], E (&yb)[ITERS][R], const E (&xb_)[ITERS][R], auto twisted_, const Tw* tab) TN_INL {
+    constexpr bool TWISTED = decltype(twisted_)::value;
+    TwRaw rec[ITERS][R];
+    if constexpr (TWISTED) fetch_records(rec, tab);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      static_for<0, R>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr (TWISTED) {
+          const Tw w = tw_pack(rec[it][e]);
+          ya[it][Ge::brvL(e)] = A::in_mul(xa_[it][e], w, ar);
+          yb[it][Ge::brvL(e)] = A::in_mul(xb_[it][e], w, ar);
+        } else {
+          ya[it][Ge::brvL(e)] = A::in_red(xa_[it][e], ar);
+          yb[it][Ge::brvL(e)] = A::in_red(xb_[it][e], ar);
+        }
+      });
+    }
+  };
   // out[row n + ls + e TP] = x[e] * (psi^-(ls + e TP) n^-1)   (kind 2; cg_ntt.py:74-75 and :91-92 in one exact product),
   //                          x[e] * n^-1 (kind 1; :74-75),  canonical x[e] (kind 0)
   const Tw ninv = AM == CGA_SHOUP ? ar.ninv : ar.fninv;            // n^-1 in the record format of the plan's tables
-  auto store_row = [&](const E (&x)[ITERS][R], u32 row, auto kind_, u32 zero, const Tw* tab) TN_INL {
+  // Untwist in two exact factors (TN_CG_UNTWIST2): psi^-(ls + e TP) n^-1 = psi^-(e TP) [the same for every lane-step: scalar
+  // loads] x psi^-ls n^-1 [one record per lane-step, loaded once per persistent workgroup].  One more multiplication per
+  // coefficient (exact, so the same residue) instead of R record loads per row whose L2 latency nothing covers at the end
+  // of a row (measured: gpurun_out stamps, 4.7k of 40k cycles per row at GROUP 8).
+#ifndef TN_CG_UNTWIST2
+#define TN_CG_UNTWIST2 1
+#endif
+  TwRaw out_rec[ITERS];
+  if (TN_CG_UNTWIST2 && mode == CG_POLYMUL) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      if (is_live(it)) out_rec[it] = ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(psi_inv_ninv)) + lane_step(it));
+  }
+  // v[e] = the canonical output coefficient of column e
+  auto finish_row = [&](E (&v)[ITERS][R], const E (&x)[ITERS][R], auto kind_, u32 zero, const Tw* tab) TN_INL {
     constexpr int KIND = decltype(kind_)::value;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       if (!is_live(it)) continue;
       const u32 tl = opaque_copy(lane_step(it));
-      E v[R];
+      (void)tl;
       if constexpr (KIND == 2) {
         static_for<0, R>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
-          v[e] = A::out_mul(x[it][e], tw_pack(ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(tab + ((u32)e << cs)) + tl))), ar);
+#if defined(TN_CG_ABL_NOREC)
+          v[it][e] = A::out_mul(x[it][e], ninv, ar);
+#elif TN_CG_UNTWIST2
+          const Tw* up = psi_inv_pow + zero;                        // (zero: keeps the R uniform records out of registers across the row loop)
+          v[it][e] = A::out_mul(e ? A::in_mul(x[it][e], up[(u32)e << cs], ar) : x[it][e], tw_pack(out_rec[it]), ar);
+#else
+          v[it][e] = A::out_mul(x[it][e], tw_pack(ld_global(reinterpret_cast<const TN_GLOBAL_AS TwRaw*>(uniform_ptr(tab + ((u32)e << cs)) + tl))), ar);
+#endif
         });
       } else if constexpr (KIND == 1) {
 #pragma unroll
-        for (int e = 0; e < R; ++e) v[e] = A::out_mul(x[it][e], ninv, ar);
+        for (int e = 0; e < R; ++e) v[it][e] = A::out_mul(x[it][e], ninv, ar);
       } else {
 #pragma unroll
-        for (int e = 0; e < R; ++e) v[e] = A::out_canon(x[it][e], ar);
+        for (int e = 0; e < R; ++e) v[it][e] = A::out_canon(x[it][e], ar);
       }
+    }
+  };
+  auto emit_row = [&](const E (&v)[ITERS][R], u32 row, u32 zero) TN_INL {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      if (!is_live(it)) continue;
+      const u32 tl = opaque_copy(lane_step(it));
 #pragma unroll
       for (int e = 0; e < R; ++e) {
         TN_GLOBAL_AS E* cp = uniform_ptr(out + ((size_t)row << logn) + ((u32)e << cs) + zero);
 #if TN_CG_NT_STREAM
-        __builtin_nontemporal_store(v[e], cp + tl);
+        __builtin_nontemporal_store(v[it][e], cp + tl);
 #else
-        cp[tl] = v[e];
+        cp[tl] = v[it][e];
 #endif
       }
     }
+  };
+  auto store_row = [&](const E (&x)[ITERS][R], u32 row, auto kind_, u32 zero, const Tw* tab) TN_INL {
+    E v[ITERS][R];
+    finish_row(v, x, kind_, zero, tab);
+    emit_row(v, row, zero);
   };
 
   stage_table(mode == CG_NTT_INV ? om_inv : om_fwd);
@@ -284,38 +362,101 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // before the last transform of the current row and consumed at the top of the next iteration.  One body per mode,
   // each with its switches compiled in (a run-time switch inside a body keeps both sides' registers alive).
   E xa[ITERS][R], xn[ITERS][R];
+  // AHEAD: products request BOTH operands of the next row before the inverse transform (one more row of registers while it
+  // runs); a and b are then twisted together on one fetch of the twist records and nothing at the top of a row waits for
+  // HBM.  Only at GROUP 8 (256-register budget): the smaller groups' budgets have no room for the third row (measured with
+  // it: GROUP 2 3.37 -> 3.71 ms from spills, GROUP 4 would not fit at all; GROUP 8 2.87 -> 2.80 ms).
+#ifndef TN_CG_AHEAD
+#define TN_CG_AHEAD 1
+#endif
+  constexpr bool AHEAD = TN_CG_AHEAD && GROUP == 8;
+  E xm[AHEAD ? ITERS : 1][R];
   u32 row = blockIdx.x;
-  if (row < batch) load_row(xn, a, row, 0u);
+  if (row < batch) {
+    load_row(xn, a, row, 0u);
+    if constexpr (AHEAD) { if (mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL) load_row(xm, b, row, 0u); }
+  }
   // nwc_poly_mult (cg_ntt.py:78-92); untwisted: the same chain without twist / untwist = python_poly_mult
   // (test/cocotb_tests/test_ntt_poly_mult.py:38-43), what the RTL / RoCC accelerator computes
+  // The result of row k is stored AFTER the twist of row k+1 (software-pipelined): vector-memory operations retire in order and
+  // the compiler drains them all at the loop back-edge, so stores issued at the bottom of a row expose their latency there on
+  // every row (measured: ~950 of 40k cycles); issued here they drain behind the transforms.  (First row: the zero-initialised
+  // registers go to this row's own slot, which the same thread overwrites one iteration later; no branch at the loop top.)
+#ifndef TN_CG_DEFER
+#define TN_CG_DEFER 0            // off: the extra row of registers across the back-edge spills at every GROUP (A/B: profiles/README.md)
+#endif
+  constexpr bool DEFER = TN_CG_DEFER != 0;
+  E vprev[DEFER ? ITERS : 1][R];
+  u32 prev_row = blockIdx.x;
+  bool have_prev = false;
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+      for (int e = 0; e < R; ++e) vprev[it][e] = 0;
+  }
   auto product_row = [&](auto twisted_, u32 nrow, u32 zero, const Tw* tw_in, const Tw* tw_out) TN_INL {
     constexpr bool TWISTED = decltype(twisted_)::value;
     E xb[ITERS][R];
-    // vector-memory operations retire in order: b's row (HBM) is requested AFTER the twist of a has consumed its records
-    // (L2), so that nothing of a's path waits for HBM; b stays in flight while a is transformed
-    enter(xa, xn, twisted_, tw_in);                                // :82
-    sched_fence();
-    load_row(xb, b, row, zero);
-    sched_fence();
-    transform(xa, om_fwd, false, nullptr);                         // :86  A^ stays in registers
-    sched_fence();                                                 // (or the scheduler requests b's twist records a whole transform early)
-    enter(xn, xb, twisted_, tw_in);                                // :83
-    transform(xn, om_fwd, false, nullptr);                         // :87
+    if constexpr (AHEAD) {
+      TN_STAMP(7);
+      enter2(xa, xn, xb, xm, twisted_, tw_in);                     // :82-83
+      if constexpr (DEFER) { sched_fence(); emit_row(vprev, prev_row, zero); sched_fence(); }
+      TN_STAMP(0);
+      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
+      TN_STAMP(1);
+      transform(xb, om_fwd, false, nullptr);                       // :87
+      TN_STAMP(2);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      if (!is_live(it)) continue;
-      static_for<0, R>([&](auto e_) {                              // :88, left in the inverse's first-trip order (bit_reverse_list of :73)
-        constexpr int e = decltype(e_)::value;
-        xb[it][Ge::brvL(e)] = A::pointwise(xa[it][e], xn[it][e], ar);
-        if constexpr ((e & 1) == 1) sched_fence();                 // two products in flight at a time
-      });
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        E c[R];
+        static_for<0, R>([&](auto e_) {                            // :88
+          constexpr int e = decltype(e_)::value;
+          c[e] = A::pointwise(xa[it][e], xb[it][e], ar);
+          if constexpr ((e & 1) == 1) sched_fence();               // two products in flight at a time
+        });
+        static_for<0, R>([&](auto e_) { constexpr int e = decltype(e_)::value; xb[it][Ge::brvL(e)] = c[e]; });   // the inverse's first-trip order (bit_reverse_list of :73)
+      }
+      load_row(xn, a, nrow, zero);
+      load_row(xm, b, nrow, zero);
+      TN_STAMP(3);
+    } else {
+      // vector-memory operations retire in order: b's row (HBM) is requested AFTER the twist of a has consumed its records
+      // (L2), so that nothing of a's path waits for HBM; b stays in flight while a is transformed
+      enter(xa, xn, twisted_, tw_in);                              // :82
+      sched_fence();
+      if constexpr (DEFER) emit_row(vprev, prev_row, zero);
+      load_row(xb, b, row, zero);
+      sched_fence();
+      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
+      sched_fence();                                               // (or the scheduler requests b's twist records a whole transform early)
+      enter(xn, xb, twisted_, tw_in);                              // :83
+      transform(xn, om_fwd, false, nullptr);                       // :87
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (!is_live(it)) continue;
+        static_for<0, R>([&](auto e_) {                            // :88, left in the inverse's first-trip order (bit_reverse_list of :73)
+          constexpr int e = decltype(e_)::value;
+          xb[it][Ge::brvL(e)] = A::pointwise(xa[it][e], xn[it][e], ar);
+          if constexpr ((e & 1) == 1) sched_fence();               // two products in flight at a time
+        });
+      }
+      load_row(xn, a, nrow, zero);
     }
-    load_row(xn, a, nrow, zero);
     if (restage) { __syncthreads(); stage_table(om_inv); }         // (the transform's first barrier orders the staging before its first read)
     transform(xb, om_inv, !restage, nullptr);                      // :90 (:72-73)
+    TN_STAMP(4);
     sched_fence();
-    if constexpr (TWISTED) store_row(xb, row, K2(), zero, tw_out);  // :74-75 and :91-92 in one exact product
-    else store_row(xb, row, K1(), zero, tw_out);
+    if constexpr (DEFER) {
+      if constexpr (TWISTED) finish_row(vprev, xb, K2(), zero, tw_out);   // :74-75 and :91-92 in one exact product
+      else finish_row(vprev, xb, K1(), zero, tw_out);
+      prev_row = row; have_prev = true;
+    } else {
+      if constexpr (TWISTED) store_row(xb, row, K2(), zero, tw_out);
+      else store_row(xb, row, K1(), zero, tw_out);
+    }
+    TN_STAMP(5);
     if (restage) { __syncthreads(); stage_table(om_fwd); }
   };
   for (; row < batch; row += gridDim.x) {
@@ -335,7 +476,26 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       else { transform(xa, om_fwd, false, tr); store_row(xa, row, K0(), zero, tw_out); }
     }
   }
+  if constexpr (DEFER) { if (have_prev) emit_row(vprev, prev_row, 0u); }
+#ifdef TN_CG_STAMPS
+  if (trace && (mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL) && (threadIdx.x & 63) == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(trace) + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;
+    for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    o[8] = st_bar; o[9] = __builtin_amdgcn_s_memtime() - st_begin; o[10] = __builtin_amdgcn_s_memrealtime(); o[11] = st_begin;
+  }
+#endif
 }
+
+#ifdef TN_CG_STAMPS
+// diagnostic builds: one device buffer for the stamps of the last product launch, read back by tn_debug_cg_stamps()
+inline void*& tn_cg_stamp_ptr() { static void* p = nullptr; return p; }
+inline size_t& tn_cg_stamp_size() { static size_t n = 0; return n; }
+inline void* tn_cg_stamp_buffer(size_t bytes) {
+  if (bytes > tn_cg_stamp_size()) { if (tn_cg_stamp_ptr()) (void)hipFree(tn_cg_stamp_ptr()); (void)hipMalloc(&tn_cg_stamp_ptr(), bytes); tn_cg_stamp_size() = bytes; }
+  (void)hipMemset(tn_cg_stamp_ptr(), 0, bytes);
+  return tn_cg_stamp_ptr();
+}
+#endif
 
 // Launch one slice.  Returns hipErrorInvalidValue for shapes the instantiation cannot run (the dispatcher in cg_launch.hip
 // only asks for valid ones).
@@ -364,8 +524,11 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
   const u32 grid = (u32)(batch < resident ? batch : resident);
   const PlanView<E> pv = make_view<E>(p);
   if (p->general) mode |= CG_FLAG_RESTAGE;
+#ifdef TN_CG_STAMPS
+  if (!trace && (mode & 0xff) == CG_POLYMUL) trace = tn_cg_stamp_buffer((size_t)grid * (threads / 64) * 12 * sizeof(unsigned long long));
+#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, pv.ar, logn, mode, pv.omega_pow, pv.omega_inv_pow, pv.psi_pow,
-                     pv.psi_inv_ninv, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch);
+                     pv.psi_inv_ninv, pv.psi_inv_pow, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch);
   return hipGetLastError();
 }
 

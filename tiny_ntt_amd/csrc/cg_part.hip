@@ -71,3 +71,13 @@ hipError_t launch_cg_part6(const tn_plan* p, int mode, int, int layout, bool, co
 #endif
 
 }  // namespace tn
+
+#if defined(TN_CG_STAMPS) && TN_CG_PART == 6
+// diagnostic builds only (tools/gpu_cg_stamps.py): the stamps of the last constant-geometry product launch
+extern "C" size_t tn_debug_cg_stamps(void* host, size_t max_bytes) {
+  (void)hipDeviceSynchronize();
+  const size_t nb = tn::tn_cg_stamp_size() < max_bytes ? tn::tn_cg_stamp_size() : max_bytes;
+  if (nb) (void)hipMemcpy(host, tn::tn_cg_stamp_ptr(), nb, hipMemcpyDeviceToHost);
+  return nb;
+}
+#endif

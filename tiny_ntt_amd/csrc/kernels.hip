@@ -205,6 +205,13 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
 
 template <typename E> struct alignas(2 * sizeof(E)) PairOf { E lo, hi; };
 
+#ifdef TN_FUSED_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/gpu_fused_clock.py; MI355X_MICROARCH.md, DVFS give-back item 6): every workgroup of the product
+// kernel stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once before and once after its row loop into an array
+// of its own in the code object; nothing in the kernel reads it and no output depends on it.  The shipped library has no stamp.
+__device__ unsigned long long tn_fused_stamps[4 * 4096];
+#endif
+
 template <typename E, typename Cfg>
 __device__ __forceinline__ E ld_operand(const E* __restrict__ p, u32 row, u32 tau, int r) {
 #if TN_ABL_NO_GLOBAL
@@ -277,6 +284,9 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // product) while the inverse transform of the current row runs; b itself is requested at the
   // top of the row and not needed until a's forward transform is done.
   E xa[Cfg::R], xb[Cfg::R];
+#ifdef TN_FUSED_STAMPS
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   u32 row = blockIdx.x * chunk;
   u32 taken = 1;                            // rows taken from the current chunk           (both workgroup-uniform: scalar registers)
   u32 chunk_id = blockIdx.x;                // fixed-stride mode: the chunk being processed
@@ -379,6 +389,12 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
     row = next;
   }
   if (have_c) st_result<E, Cfg>(c, prev, tau, xa);
+#ifdef TN_FUSED_STAMPS
+  if (tau == 0 && blockIdx.x < 4096) {
+    tn_fused_stamps[4 * blockIdx.x + 0] = st_t0; tn_fused_stamps[4 * blockIdx.x + 1] = st_r0;
+    tn_fused_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime(); tn_fused_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   // the last workgroup to run out of rows re-arms the counters for the next launch that uses this slot
   if (sched && tau == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
 }
@@ -787,3 +803,12 @@ hipError_t launch_checksum(const tn_plan* p, const void* src, u64* out, size_t b
 }
 
 }  // namespace tn
+
+#ifdef TN_FUSED_STAMPS
+extern "C" size_t tn_debug_fused_stamps(void* host, size_t max_bytes) {
+  (void)hipDeviceSynchronize();
+  const size_t nb = sizeof(tn::tn_fused_stamps) < max_bytes ? sizeof(tn::tn_fused_stamps) : max_bytes;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tn::tn_fused_stamps), nb, 0, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return nb;
+}
+#endif
