@@ -22,6 +22,13 @@
 // every lambda of the kernel body must be inlined: a call would pass the captured register arrays through scratch memory
 #define TN_INL __attribute__((always_inline))
 
+#ifndef TN_CG_PINGPONG_MAXG
+#define TN_CG_PINGPONG_MAXG 0
+#endif
+#ifndef TN_CG_CT_THREADS
+#define TN_CG_CT_THREADS 0       // > 0: threads per polynomial of the n = 4096 kernels whatever the GROUP (see CgShape)
+#endif
+
 namespace tn {
 
 constexpr int CG_FLAG_RESTAGE = 0x100;   // or-ed into the kernel's mode: omega^(n/2) != -1 (any-psi plans): the inverse transform of a
@@ -30,19 +37,26 @@ constexpr int CG_FLAG_RESTAGE = 0x100;   // or-ed into the kernel's mode: omega^
 // Lane-steps one thread runs per trip.  Workgroups have n / (2 GROUP) threads up to 1024; beyond that a thread takes
 // several lane-steps (GROUP = 1: two at n = 4096).  BIG: the n = 8192 instantiations of GROUP 1 and 2 (twice the
 // lane-steps per thread; own kernels so that the n <= 4096 ones keep their register budget).
-template <typename E, int GROUP, bool BIG> struct CgShape {
+// CTLOGN = 12 (n = 4096 compiled in: the sweep of BASELINE config 5): TN_CG_CT_THREADS threads per polynomial whatever the
+// GROUP, i.e. 4096 / (2 GROUP) / threads lane-steps per thread.
+template <typename E, int GROUP, bool BIG, int CTLOGN = 0> struct CgShape {
   static constexpr int R = 2 * GROUP;
+  static constexpr bool FIXED = CTLOGN == 12 && TN_CG_CT_THREADS > 0 && (4096 / R) > TN_CG_CT_THREADS;
   static constexpr int MAXN = BIG ? 8192 : (GROUP >= 4 ? 8192 : 4096);
-  static constexpr int ITERS = (MAXN / R) > 1024 ? (MAXN / R) / 1024 : 1;
-  static constexpr int THREADS_MAX = (MAXN / R) > 1024 ? 1024 : (MAXN / R);
+  static constexpr int ITERS = FIXED ? (4096 / R) / (TN_CG_CT_THREADS > 0 ? TN_CG_CT_THREADS : 1) : ((MAXN / R) > 1024 ? (MAXN / R) / 1024 : 1);
+  static constexpr int THREADS_MAX = FIXED ? TN_CG_CT_THREADS : ((MAXN / R) > 1024 ? 1024 : (MAXN / R));
   // waves per SIMD the register allocator leaves room for = what two workgroups per CU (the LDS limit at n = 4096 / 64-bit)
   // amount to: GROUP 8: 2 x 256 threads -> 2 (<= 256 VGPRs: 16 coefficients, 16 of A^ and 16 prefetched per thread);
   // GROUP 4: 2 x 512 -> 4; GROUP 1, 2: 2 x 1024 -> 8; BIG: one workgroup per CU -> 4
-  static constexpr int MIN_WAVES = BIG ? 4 : (GROUP >= 8 ? 2 : (GROUP == 4 ? 4 : 8));
+  static constexpr int MIN_WAVES = FIXED ? (2 * TN_CG_CT_THREADS / 256 < 1 ? 1 : 2 * TN_CG_CT_THREADS / 256)
+                                         : BIG ? 4 : (GROUP >= 8 ? 2 : (GROUP == 4 ? 4 : (GROUP <= TN_CG_PINGPONG_MAXG ? 4 : 8)));
+  // GROUP <= TN_CG_PINGPONG_MAXG: two images used alternately, ONE barrier per transpose (a stage per trip at GROUP 1 leaves no
+  // arithmetic to hide a second barrier behind); 96 KiB per workgroup at n = 4096 / 64-bit -> one workgroup per CU
+  static constexpr bool PINGPONG = !BIG && GROUP <= TN_CG_PINGPONG_MAXG;
 };
 
 template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
-__global__ void __launch_bounds__((CgShape<E, GROUP, BIG>::THREADS_MAX), (CgShape<E, GROUP, BIG>::MIN_WAVES))
+__global__ void __launch_bounds__((CgShape<E, GROUP, BIG, CTLOGN>::THREADS_MAX), (CgShape<E, GROUP, BIG, CTLOGN>::MIN_WAVES))
 cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>::type* __restrict__ om_fwd,
           const typename TwOf<E>::type* __restrict__ om_inv, const typename TwOf<E>::type* __restrict__ psi_pow,
           const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const typename TwOf<E>::type* __restrict__ psi_inv_pow,
@@ -54,7 +68,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   typedef typename TwOf<E>::type Tw;
   typedef CgPair<E> Pair;
   typedef typename TwRawOf<E>::type TwRaw;
-  constexpr int R = Ge::R, L = Ge::L, ITERS = CgShape<E, GROUP, BIG>::ITERS;
+  constexpr int R = Ge::R, L = Ge::L, ITERS = CgShape<E, GROUP, BIG, CTLOGN>::ITERS;
   const u32 logn = CTLOGN ? (u32)CTLOGN : logn_rt;
   const u32 n = 1u << logn, TP = n >> L;                          // TP: lane-steps per polynomial
   const u32 cs = logn - L;                                        // log2 TP: column e of a lane-step starts at e << cs
@@ -65,8 +79,11 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   const bool restage = (mode_flags & CG_FLAG_RESTAGE) != 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  constexpr bool PINGPONG = CgShape<E, GROUP, BIG, CTLOGN>::PINGPONG;
+  const u32 img_elems = (M::span(n) + 3u) & ~3u;
   E* img = reinterpret_cast<E*>(tn_smem);
-  Tw* ltab = reinterpret_cast<Tw*>(img + ((M::span(n) + 3u) & ~3u));
+  Tw* ltab = reinterpret_cast<Tw*>(img + (PINGPONG ? 2u : 1u) * img_elems);
+  u32 pp = 0;                                                     // ping-pong: element offset of the image the next transpose writes
   auto stage_table = [&](const Tw* __restrict__ src) TN_INL {            // omega^j (or omega^-j), j <= n/2
     for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<GROUP, LAYOUT>(j, big)] = src[j];
   };
@@ -126,8 +143,9 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     // Two workgroup barriers per LDS transpose, both around the WRITE: one before it (every wave has read what the image
     // held: the previous trip's columns, or the previous transform's) and one after it (the columns are in the image).
     // A wave's reads are followed by its arithmetic, not by a barrier, so no wave waits at a barrier for LDS latency.
+    E* wimg = img + pp;                                             // the image this transpose goes through
     if (ntrips > 1) {
-      TN_BARRIER();
+      if constexpr (!PINGPONG) TN_BARRIER();
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         if (!is_live(it)) continue;
@@ -136,10 +154,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         if (CTLOGN && r1 == (u32)L) {                              // full first trip: columns T + e TP
           const u32 aT = M::at(T);
 #pragma unroll
-          for (int e = 0; e < R; ++e) img[M::col(aT, e, cs)] = x[it][e];
+          for (int e = 0; e < R; ++e) wimg[M::col(aT, e, cs)] = x[it][e];
         } else {
 #pragma unroll
-          for (int e = 0; e < R; ++e) img[M::at(Ge::pos(logn, (int)r1, T, e))] = x[it][e];
+          for (int e = 0; e < R; ++e) wimg[M::at(Ge::pos(logn, (int)r1, T, e))] = x[it][e];
         }
       }
     }
@@ -152,7 +170,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         const u32 base = M::at((u32)R * opaque_copy(lane_step(it)));
 #pragma unroll
         for (int e = 0; e < R; e += 2) {
-          const Pair v = *reinterpret_cast<const Pair*>(img + M::step(base, e));
+          const Pair v = *reinterpret_cast<const Pair*>(wimg + M::step(base, e));
           x[it][e] = v.lo; x[it][e + 1] = v.hi;
         }
       }
@@ -199,16 +217,18 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         } else run(std::integral_constant<int, 0>());
       }
       if (trip + 1 < ntrips) {
-        TN_BARRIER();                                           // every wave has read this trip's input
+        if constexpr (PINGPONG) { pp ^= img_elems; wimg = img + pp; }      // the other image: slower waves may still be reading this one
+        else TN_BARRIER();                                      // every wave has read this trip's input
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           if (!is_live(it)) continue;
           const u32 T = opaque_copy(lane_step(it)), aT = M::at(T);
 #pragma unroll
-          for (int e = 0; e < R; ++e) img[CTLOGN ? M::col(aT, e, cs) : M::at(T + ((u32)e << cs))] = x[it][e];
+          for (int e = 0; e < R; ++e) wimg[CTLOGN ? M::col(aT, e, cs) : M::at(T + ((u32)e << cs))] = x[it][e];
         }
       }
     }
+    if constexpr (PINGPONG) pp ^= img_elems;                         // the next transform starts in the image this one did not use last
   };
 
   // Operand and table accesses are "uniform base (row, column e: scalar unit) + the lane-step as a 32-bit offset"; the
@@ -503,14 +523,14 @@ template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
 static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
                               hipStream_t s) {
   typedef CgMap<E, GROUP, LAYOUT> M;
-  typedef CgShape<E, GROUP, BIG> Sh;
+  typedef CgShape<E, GROUP, BIG, CTLOGN> Sh;
   typedef typename TwOf<E>::type Tw;
   const u32 n = p->n, logn = p->logn;
   if ((int)logn < CgGeom<GROUP>::L || (CTLOGN && (int)logn != CTLOGN)) return hipErrorInvalidValue;
   const u32 tp = n / Sh::R;
   u32 threads = tp < 64 ? 64 : (tp > (u32)Sh::THREADS_MAX ? (u32)Sh::THREADS_MAX : tp);
   if ((tp + threads - 1) / threads > (u32)Sh::ITERS) return hipErrorInvalidValue;
-  const size_t lds_bytes = (size_t)((M::span(n) + 3u) & ~3u) * sizeof(E) + (size_t)(n / 2 + 1) * sizeof(Tw);
+  const size_t lds_bytes = (size_t)(Sh::PINGPONG ? 2 : 1) * ((M::span(n) + 3u) & ~3u) * sizeof(E) + (size_t)(n / 2 + 1) * sizeof(Tw);
   auto kern = cg_kernel<E, GROUP, LAYOUT, AM, BIG, CTLOGN>;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {
