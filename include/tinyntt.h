@@ -84,6 +84,12 @@ typedef struct tn_plan tn_plan;
 /* Plan flags */
 #define TN_PLAN_DEFAULT 0u
 #define TN_PLAN_FORCE_CANONICAL 1u /* disable lazy reduction in the FUSED kernel (debug / generic-modulus path) */
+/* The caller PROMISES that every input coefficient of tn_poly_mult_* is already in [0, q) — the precondition of the reference's
+ * C++ path (mod_add / mod_sub / mod_mul, benchmark_ntt_60bit.cpp:66-77, on make_poly's output :79-87); the Python path reduces
+ * with % (cg_ntt.py:82-83) and needs no promise.  The fused product kernel at n = 4096 / 64-bit lanes then skips the input
+ * folds (bound schedule started from q, replayed exactly at plan creation); every other kernel ignores the flag.  With the flag
+ * set, inputs >= q give undefined results. */
+#define TN_PLAN_CANONICAL_INPUTS 2u
 
 /*
  * Create a plan for (n, q, psi) on HIP device `device`.

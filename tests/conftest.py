@@ -206,11 +206,14 @@ class Emu:
         L.emu_split_sched_ok.argtypes = [u32, u64]; L.emu_split_sched_ok.restype = ctypes.c_int
         L.emu_split_sched_stat.argtypes = [ctypes.c_int, ctypes.c_int]; L.emu_split_sched_stat.restype = ctypes.c_long
 
-    def fused(self, n, q, psi, a, b, canonical=False, cyclic=False):
+    def fused(self, n, q, psi, a, b, canonical=False, cyclic=False, promised_canonical_inputs=False):
         a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
         a2, b2 = np.atleast_2d(a), np.atleast_2d(b)
         c = np.empty_like(a2)
-        rc = self.lib.emu_fused_poly_mult(n, q, psi, int(canonical) | (2 if cyclic else 0), p64(a2), p64(b2), p64(c), a2.shape[0])
+        rc = self.lib.emu_fused_poly_mult(n, q, psi, int(canonical) | (2 if cyclic else 0) | (4 if promised_canonical_inputs else 0),
+                                          p64(a2), p64(b2), p64(c), a2.shape[0])
+        if rc == 7:
+            return None
         assert rc == 0, rc
         return c.reshape(a.shape)
 

@@ -15,10 +15,10 @@ using namespace tn;
 
 namespace {
 
-template <typename E, int LOGN, int LPT, bool LAZY>
+template <typename E, int LOGN, int LPT, bool LAZY, bool CIN = false>
 int fused_polymul_emu(const HostTables& t, const u64* a, const u64* b, u64* c, size_t batch, bool cyclic) {
   typedef FusedCfg<E, LOGN, LPT> Cfg;
-  typedef Policy<E, LAZY> Pol;
+  typedef Policy<E, LAZY, CIN> Pol;
   typedef typename TwOf<E>::type Tw;
   Arith<E> ar = h_make_arith<E>(t);
   if (cyclic) ar.fninv_w1 = ar.fninv;                      // as launch_fused_t: product in Z_q[x]/(x^n - 1)
@@ -349,12 +349,16 @@ bool params_ok(u32 n, u64 q, u64 psi) {
 extern "C" {
 
 // 0 ok, 2 bad params, 7 unsupported n.  Coefficients travel as uint64 regardless of lane width.
-// flags: bit 0 = canonical policy, bit 1 = cyclic product (x^n - 1) instead of negacyclic.
+// flags: bit 0 = canonical policy, bit 1 = cyclic product (x^n - 1) instead of negacyclic, bit 2 = inputs promised canonical.
 int emu_fused_poly_mult(uint32_t n, uint64_t q, uint64_t psi, int flags, const uint64_t* a, const uint64_t* b,
                         uint64_t* c, size_t batch) {
   if (!params_ok(n, q, psi)) return 2;
   const bool cyc = (flags & 2) != 0;
   const HostTables t = h_build_tables(n, q, psi, !(flags & 1));
+  if (flags & 4) {                       // promised-canonical inputs (TN_PLAN_CANONICAL_INPUTS): n = 4096, lazy 64-bit lanes, schedule replayed
+    if (!(t.cin_ok && t.logn == 12 && t.lazy && t.elem_bytes == 8) || cyc) return 7;
+    return fused_polymul_emu<u64, 12, fused_lpt(12), true, true>(t, a, b, c, batch, false);
+  }
   if (t.elem_bytes == 8) return t.lazy ? fused_dispatch<u64, true>(t, a, b, c, batch, cyc) : fused_dispatch<u64, false>(t, a, b, c, batch, cyc);
   return t.lazy ? fused_dispatch<u32, true>(t, a, b, c, batch, cyc) : fused_dispatch<u32, false>(t, a, b, c, batch, cyc);
 }

@@ -34,6 +34,22 @@ def test_fused_emulation_random_and_unreduced_vs_oracle(emu, oracle, tag):
         assert np.array_equal(emu.fused(n, q, psi, a, b, canonical=canonical), ref)
 
 
+def test_fused_emulation_with_promised_canonical_inputs(emu, oracle, golden):
+    """TN_PLAN_CANONICAL_INPUTS: the n = 4096 / 60-bit product kernel with the bound schedule started from q (no load folds):
+    golden products and the extreme canonical values (all q - 1, all 0, random)."""
+    g = golden("P4096_60")
+    n, q, psi = g.n, g.q, g.psi
+    for name in g.cases("poly_mult"):
+        a, b = g[name + "_a"], g[name + "_b"]
+        if a.max() < q and b.max() < q:
+            assert np.array_equal(emu.fused(n, q, psi, a, b, promised_canonical_inputs=True), g[name + "_c"]), name
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, q, (4, n), dtype=np.uint64); b = rng.integers(0, q, (4, n), dtype=np.uint64)
+    a[0] = q - 1; b[0] = q - 1; a[1] = q - 1; b[2] = 0
+    assert np.array_equal(emu.fused(n, q, psi, a, b, promised_canonical_inputs=True), oracle.poly_mult(a, b, q, psi))
+    assert emu.fused(256, 8380417, 1239911, a[0, :256] % np.uint64(8380417), a[0, :256] % np.uint64(8380417), promised_canonical_inputs=True) is None
+
+
 def test_lazy_policy_selected_for_reference_moduli(emu):
     for tag in FUSED_TAGS:
         assert emu.lib.emu_is_lazy(*PARAMS[tag]) == 1, tag

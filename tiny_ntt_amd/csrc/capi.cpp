@@ -108,6 +108,7 @@ static tn_status plan_new(tn_plan** out, PlanKind kind, uint32_t n, uint64_t q, 
   p->n = n; p->logn = logn; p->q = q; p->psi = kind == PLAN_OMEGA ? 0 : t.psi; p->omega = t.omega;
   p->device = device; p->flags = flags; p->elem_bytes = elem_bytes;
   p->k = t.k; p->lazy = t.lazy; p->cg_lazy = t.cg_lazy; p->cg_sched = t.cg_sched;
+  p->canonical_inputs = kind == PLAN_PSI && (flags & TN_PLAN_CANONICAL_INPUTS) && t.cin_ok;
   p->omega_only = kind == PLAN_OMEGA; p->general = kind != PLAN_PSI;       // (no reversal trick without omega^(n/2) == -1)
   if (elem_bytes == 8) p->ar64 = h_make_arith<u64>(t); else p->ar32 = h_make_arith<u32>(t);
   p->has_fused = kind == PLAN_PSI && fused_supported(logn, elem_bytes);

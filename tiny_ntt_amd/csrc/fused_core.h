@@ -183,14 +183,18 @@ template <typename E> struct LazyTraits;
 template <> struct LazyTraits<u64> { static constexpr int LIMIT = 16, TMUL = 4, PW = 2; };   // (TMUL: canonical policy's Shoup product, unused by the split path)
 template <> struct LazyTraits<u32> { static constexpr int LIMIT = 64, TMUL = 2, PW = 4; };   // mul_tw_lazy < 2q
 
-template <typename E, bool LAZY> struct Policy {
+// CIN (lazy 64-bit lanes only): the caller PROMISES canonical inputs (TN_PLAN_CANONICAL_INPUTS): load() folds nothing and the
+// bound schedule starts from q instead of "any word" (SplitSched<Cfg, true>).
+template <typename E, bool LAZY, bool CIN = false> struct Policy {
   typedef typename TwOf<E>::type Tw;
   static constexpr bool lazy = LAZY;
+  static constexpr bool canonical_inputs = CIN && LAZY && sizeof(E) == 8;
   static constexpr bool split = LAZY && sizeof(E) == 8;
   static constexpr int LIMIT = LazyTraits<E>::LIMIT, TMUL = LazyTraits<E>::TMUL, PW = LazyTraits<E>::PW;
 
   // an arbitrary word -> a bounded lazy value (< 2^k + eps) or a canonical one
   TN_HD static E load(E x, const Arith<E>& ar) {
+    if (canonical_inputs) return x;
     if (LAZY) return fold(x, ar.k, ar.fold_c);
     return mul_tw(x, ar.one, ar.q);
   }
@@ -287,7 +291,7 @@ template <typename P, int LOGN> struct Sched {
 //                         folded first; outputs u + v, tmax(u + Kv q)
 // The decisions are compile-time guesses in coarse units; h_split_sched_ok() (plan_tables.h) replays them with
 // exact 128-bit bounds for the plan's (k, c), and a plan whose modulus fails that replay is not lazy.
-template <typename Cfg> struct SplitSched {
+template <typename Cfg, bool CIN = false> struct SplitSched {
   static constexpr int LOGN = Cfg::LOGN, R = Cfg::R;
   static constexpr long U = 4096, CAP = 16 * U;
   static constexpr long FOLDED = U + 1;            // fold(): < 2^k + 2^(64-k) c
@@ -313,8 +317,9 @@ template <typename Cfg> struct SplitSched {
   static constexpr Data build() {
     Data d;
     long b[R] = {};
-    // forward: load_reduce() folds the registers that enter stage 0 as "u" (the low half), the rest are raw words
-    for (int r = 0; r < R; ++r) b[r] = r < R / 2 ? FOLDED : CAP;
+    // forward: load_reduce() folds the registers that enter stage 0 as "u" (the low half), the rest are raw words;
+    // promised-canonical inputs: every register is below q
+    for (int r = 0; r < R; ++r) b[r] = CIN ? U : (r < R / 2 ? FOLDED : CAP);
     for (int s = 0; s < LOGN; ++s) {
       if (s > 0 && phase_of(s) != phase_of(s - 1)) {
         long m = 0;
@@ -376,8 +381,8 @@ template <typename Pol, typename Cfg> struct SchedOf {
   static constexpr bool pw_fold_b() { return false; }
   static constexpr bool pw_ok() { return !Pol::lazy || S::fwd_out() <= Pol::LIMIT - 2; }
 };
-template <typename Cfg> struct SchedOf<Policy<u64, true>, Cfg> {
-  typedef SplitSched<Cfg> S;
+template <typename Cfg, bool CIN> struct SchedOf<Policy<u64, true, CIN>, Cfg> {
+  typedef SplitSched<Cfg, CIN> S;
   static constexpr bool fwd_fold(int s, int r) { return S::D.ffold[s][r]; }
   static constexpr int fwd_k(int s, int r) { return S::D.fk[s][r]; }
   static constexpr bool inv_fold(int g, int r) { return S::D.ifold[g][r]; }

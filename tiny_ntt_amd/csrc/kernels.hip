@@ -42,6 +42,16 @@
                                  //    power cap gives two thirds of that back as clock (2.06 -> 1.92 GHz at 1.39 kW)
 #endif
 
+#ifndef TN_NTTF_PIN_LOGN
+#define TN_NTTF_PIN_LOGN 99      // standalone transforms: from this log2 n on, loop invariants are pinned inside the row loop (ntt_fused_kernel).  Off:
+                                 // pinning removes the 60-68 B/lane of scratch of the n = 8192 kernels and is SLOWER (0.408 vs 0.428, profiles/r3_n8192_ab.txt)
+#endif
+#ifndef TN_VEC_PREFETCH
+#define TN_VEC_PREFETCH 1         // 1: twiddles of a vector-loaded phase (n = 8192) are requested one transpose ahead (28 more registers across it)
+#endif
+#ifndef TN_FUSED_CIN
+#define TN_FUSED_CIN 0           // 1: also build the n = 4096 / 64-bit product kernel whose bound schedule assumes canonical inputs (see launch_fused_t)
+#endif
 #ifndef TN_DYNAMIC_ROWS
 #define TN_DYNAMIC_ROWS 1        // 1: persistent workgroups take their next row from a device counter (atomicAdd) instead of a fixed
                                  //    stride: workgroups do not all run at the same speed, and with a fixed share the slowest sets the time
@@ -142,7 +152,7 @@ __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwR
     TN_MARK("fwd_phase");
     TwRefs<E> tw = tw_in;
     if constexpr (KARG) tw.zero = opaque_zero();
-    if constexpr (Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p > P0) tw.mid = vec;
+    if constexpr (TN_VEC_PREFETCH && Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p > P0) tw.mid = vec;
     const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     fwd_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("fwd_other");
@@ -155,7 +165,7 @@ __device__ __forceinline__ void forward_range(E (&x)[Cfg::R], u32 tau, const TwR
     }
     if constexpr (p + 1 < P1) {
       constexpr int pn = p + 1 < Cfg::PHASES ? p + 1 : p;
-      if constexpr (Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
+      if constexpr (TN_VEC_PREFETCH && Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
         sched_fence();
         tw_fetch_vec<E, Cfg, pn>(vec, tau_g, tw.glob);
         sched_fence();
@@ -186,20 +196,22 @@ __device__ __forceinline__ void inverse_all(E (&x)[Cfg::R], u32 tau, const TwRef
     TN_MARK("inv_phase");
     TwRefs<E> tw = tw_in;
     if constexpr (KARG) tw.zero = opaque_zero();
-    if constexpr (Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p < Cfg::PHASES - 1) tw.mid = vec;
+    if constexpr (TN_VEC_PREFETCH && Cfg::tw_src(p) == Cfg::TW_VEC && FULL && p < Cfg::PHASES - 1) tw.mid = vec;
     const Arith<E>& ar = KARG ? kernarg_arith<E>(tw.zero) : ar_in;
     inv_phase<E, Cfg, Pol, p>(x, tau, tw, ar);
     TN_MARK("inv_other");
-    if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
+    // (the next phase's vector-loaded twiddles are requested BEFORE the next row's HBM prefetch: vector-memory operations return
+    //  in order, and behind the prefetch the phase would wait for HBM: n = 8192 cg_intt, profiles/r3_n8192_ab.txt)
     if constexpr (p > 0) {
       constexpr int pn = p > 0 ? p - 1 : 0;
-      if constexpr (Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
+      if constexpr (TN_VEC_PREFETCH && Cfg::tw_src(pn) == Cfg::TW_VEC && Cfg::stage_end(pn) - Cfg::stage_begin(pn) == Cfg::LPT) {
         sched_fence();
         tw_fetch_vec<E, Cfg, pn>(vec, tau, tw.glob);
         sched_fence();
       }
-      exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
     }
+    if constexpr (p == Cfg::PHASES - 1) { sched_fence(); after_first(); sched_fence(); }
+    if constexpr (p > 0) exchange<E, Cfg, p - 1, p, p - 1>(x, tau, lds);
   });
 }
 
@@ -253,7 +265,7 @@ constexpr int polymul_waves() {
   return LPT >= 4 ? 2 : (sizeof(E) == 8 && LOGN == 12 && LAZY) ? TN_POLYMUL60_WAVES : TN_FUSED_MIN_WAVES;
 }
 
-template <typename E, int LOGN, int LPT, bool LAZY>
+template <typename E, int LOGN, int LPT, bool LAZY, bool CIN = false>
 __global__ void __launch_bounds__((1 << (LOGN - LPT)), (polymul_waves<E, LOGN, LPT, LAZY>()))
 polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ tab_fwd,
                      const typename TwOf<E>::type* __restrict__ tab_inv, const E* __restrict__ a, const E* __restrict__ b,
@@ -262,7 +274,7 @@ polymul_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict
   // compiler can prove the stores to c never alias them: wave-uniform twiddle loads then become
   // scalar loads (s_load_dwordx4) instead of vector loads that every wave would wait on.
   typedef FusedCfg<E, LOGN, LPT> Cfg;
-  typedef Policy<E, LAZY> Pol;
+  typedef Policy<E, LAZY, CIN> Pol;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
   E* lds = reinterpret_cast<E*>(tn_smem);
   typedef typename TwOf<E>::type Tw;
@@ -449,13 +461,19 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
   }
   for (u32 it = 0; row < batch; ++it) {
     if (tau == 0) take_next(next, it & 1u);              // read back after this row's barrier(s)
+    // (as in the product kernel: an opaque zero / thread index per row keep the uniform twiddle loads, the arithmetic constants
+    //  and the operand addresses inside the row loop instead of in registers across it — at n = 8192 they spilled: 60-68 B/lane)
+    constexpr bool PIN = LOGN >= TN_NTTF_PIN_LOGN;
+    const u32 zero = PIN ? opaque_zero() : 0u;
+    const u32 tl = PIN ? opaque_copy(tau) : tau;
+    constexpr bool KARG = PIN && TN_KARG_ARITH != 0;
     E x[Cfg::R];
 #pragma unroll
     for (int r = 0; r < Cfg::R; ++r) x[r] = xn[r];
     sched_fence();
     if (MODE != FNTT_CYCLIC_INV && next < batch) {
 #pragma unroll
-      for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tau, r);
+      for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tl, r);
     }
     sched_fence();
     if (MODE == FNTT_CYCLIC_INV) {
@@ -467,17 +485,17 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) x[r] = nat[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))];
       Tw pre[Cfg::NPRE];
-      tw_prefetch<E, Cfg>(pre, tau, tab);
-      const TwRefs<E> tw = {tab, lds_tab, pre};
+      tw_prefetch<E, Cfg>(pre, tl, tab);
+      const TwRefs<E> tw = {tab, lds_tab, pre, nullptr, zero};
       // the inverse starts with the thread-private phase (28 registers of twiddles): the prefetch goes after it,
       // as in the product kernel
-      inverse_all<E, Cfg, Pol>(x, tau, tw, ar, lds, [&]() {
+      inverse_all<E, Cfg, Pol, KARG>(x, tau, tw, ar, lds, [&]() {
         if (next < batch) {
 #pragma unroll
-          for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tau, r);
+          for (int r = 0; r < Cfg::R; ++r) xn[r] = ld_operand<E, Cfg>(in, next, tl, r);
         }
       });
-      st_result<E, Cfg>(out, row, tau, x);
+      st_result<E, Cfg>(out, row, tl, x);
     } else {
 #pragma unroll
       for (int r = 0; r < Cfg::R / 2; ++r) x[r] = Pol::load(x[r], ar);                 // the other half is multiplied first
@@ -485,14 +503,18 @@ ntt_fused_kernel(const Arith<E> ar, const typename TwOf<E>::type* __restrict__ t
 #pragma unroll
         for (int r = Cfg::R / 2; r < Cfg::R; ++r) x[r] = Pol::load(x[r], ar);
       }
-      forward_all<E, Cfg, Pol>(x, tau, tab, lds_tab, ar, lds);
+      {
+        Tw pre[Cfg::NPRE];
+        const TwRefs<E> tw = {tab, lds_tab, pre, nullptr, zero};
+        forward_range<E, Cfg, Pol, 0, Cfg::PHASES, KARG>(x, tau, tw, ar, lds, true, tl);
+      }
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r)
         nat[Cfg::nat_addr(bitrev(Cfg::jidx(LAST, tau, r), LOGN))] = LAZY ? Pol::canon(x[r], ar) : x[r];
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < Cfg::R; ++r) x[r] = nat[Cfg::nat_addr(Cfg::jidx(0, tau, r))];
-      st_result<E, Cfg>(out, row, tau, x);
+      st_result<E, Cfg>(out, row, tl, x);
     }
     if (Cfg::THREADS <= 64) __syncthreads();             // single-wave workgroups have no barrier inside the transposes
     row = next;
@@ -566,7 +588,14 @@ static hipError_t launch_fused_t(const tn_plan* p, const void* a, const void* b,
   typedef FusedCfg<E, LOGN, LPT> Cfg;
   const size_t lds_bytes = (size_t)Cfg::lds_elems() * sizeof(E) +
                            (size_t)2 * Cfg::lds_tw_count() * sizeof(typename TwOf<E>::type) + 16;      // + the next-row slot
+  // promised-canonical inputs (TN_PLAN_CANONICAL_INPUTS): the n = 4096 / 64-bit lazy kernel has a second instantiation whose bound
+  // schedule starts from q (no load folds); every other shape ignores the promise
+  // Built only with -DTN_FUSED_CIN=1 (developer A/B, tools/gpu_ledger.py): measured 2.7 % SLOWER than the any-word kernel on the same
+  // box (same 1,963 vector instructions per wave and row, 36 instead of 8 bytes of scratch: profiles/r3_headline_ledger.txt), so the
+  // shipped library accepts the promise and runs the any-word kernel.
+  constexpr bool HAS_CIN = TN_FUSED_CIN && sizeof(E) == 8 && LOGN == 12 && LAZY;
   auto kern = polymul_fused_kernel<E, LOGN, LPT, LAZY>;
+  if constexpr (HAS_CIN) { if (p->canonical_inputs && !cyclic) kern = polymul_fused_kernel<E, LOGN, LPT, LAZY, true>; }
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;

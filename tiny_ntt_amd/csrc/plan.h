@@ -15,6 +15,7 @@ struct tn_plan {
   tn::u32 flags = 0;
   int elem_bytes = 8;
   bool has_fused = false, lazy = false, cg_lazy = false, cg_sched = false;
+  bool canonical_inputs = false;   // TN_PLAN_CANONICAL_INPUTS was given and the fused product kernel has a schedule for it (else the flag is ignored)
   bool omega_only = false;   // created by tn_plan_create_omega: no psi, only the constant-geometry transforms
   bool general = false;      // created by tn_plan_create_general: psi / q not validated, tables computed literally (cg_ntt.py:78-92 for ANY psi)
   int k = 0;            // bitlen(q)

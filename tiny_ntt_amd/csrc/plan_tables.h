@@ -13,6 +13,7 @@ struct HostTables {
   bool lazy = false;
   bool cg_lazy = false;      // lazy, 64-bit lanes, and the constant-geometry kernels may run lazy butterflies (h_cg_lazy_ok)
   bool cg_sched = false;     // ... with the static fold schedule (h_cg_sched_ok; even log2 n only)
+  bool cin_ok = false;       // the fused product kernel's schedule for promised-canonical inputs is valid (h_split_sched_cin_ok)
   u32 fold_c = 0;
   u64 n_inv = 0, ninv_w1 = 0;
   std::vector<u64> psi_pow, psi_inv_pow, psi_inv_ninv, psi_brv, psi_inv_brv, omega_pow, omega_inv_pow;
@@ -98,8 +99,8 @@ struct SplitExact {
   void fits(u128 exclusive) { if (exclusive > two64) ok = false; }
 };
 
-template <typename Cfg> inline bool h_split_sched_replay(int k, u64 c) {
-  typedef SplitSched<Cfg> S;
+template <typename Cfg, bool CIN = false> inline bool h_split_sched_replay(int k, u64 c) {
+  typedef SplitSched<Cfg, CIN> S;
   typedef unsigned __int128 u128;
   SplitExact x(k, c);
   if (!x.ok) return false;
@@ -107,7 +108,7 @@ template <typename Cfg> inline bool h_split_sched_replay(int k, u64 c) {
   const auto& D = S::D;
   u128 b[R];
   auto level = [&]() { u128 m = 0; for (int r = 0; r < R; ++r) m = b[r] > m ? b[r] : m; for (int r = 0; r < R; ++r) b[r] = m; };
-  for (int r = 0; r < R; ++r) b[r] = r < R / 2 ? x.folded(x.two64) : x.two64;       // load_reduce(): low half folded, rest raw words
+  for (int r = 0; r < R; ++r) b[r] = CIN ? (u128)x.q : (r < R / 2 ? x.folded(x.two64) : x.two64);   // load_reduce(): low half folded, rest raw words (promised-canonical inputs: all below q)
   for (int s = 0; s < LOGN; ++s) {
     if (s > 0 && S::phase_of(s) != S::phase_of(s - 1)) level();
     const int bit = 1 << S::bpos_of(s);
@@ -201,6 +202,11 @@ inline bool h_cg_sched_ok(int k, u64 c) {
   return false;
 }
 
+// ... and of the schedule for promised-canonical inputs (TN_PLAN_CANONICAL_INPUTS; built for n = 4096 only)
+inline bool h_split_sched_cin_ok(u32 logn, int k, u64 c) {
+  return logn == 12 && h_split_sched_replay<FusedCfg<u64, 12, fused_lpt(12)>, true>(k, c);
+}
+
 // Is the split-constant lazy policy valid for this (n, k, c)?  (false too when no fused kernel is built for n)
 inline bool h_split_sched_ok(u32 logn, int k, u64 c) {
   switch (logn) {
@@ -229,6 +235,7 @@ inline HostTables h_build_tables(u32 n, u64 q, u64 psi, bool allow_lazy) {
   if (!t.lazy) t.fold_c = 0;
   t.cg_lazy = t.lazy && t.elem_bytes == 8 && h_cg_lazy_ok(t.k, t.fold_c);
   t.cg_sched = t.cg_lazy && (logn & 1) == 0 && h_cg_sched_ok(t.k, t.fold_c);
+  t.cin_ok = t.lazy && t.elem_bytes == 8 && h_split_sched_cin_ok(logn, t.k, t.fold_c);
   const u64 psi_inv = h_powmod(t.psi, q - 2, q);                // modinv: cg_ntt.py:9-10, :91
   const u64 omega_inv = h_powmod(t.omega, q - 2, q);            // :72
   t.n_inv = h_powmod(n % q, q - 2, q);                          // :74

@@ -31,6 +31,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "fused": VARIANT_FUSED, "cg": VARIANT_CG, "cg8
             "cg_swizzled": 5, "cg8_swizzled": 6, "cg2": 7, "cg2_padded": 8, "cg2_swizzled": 9, "cg4": 10, "cg4_padded": 11, "cg4_swizzled": 12}
 CG_VARIANTS = tuple(k for k in VARIANTS if k.startswith("cg"))
 PLAN_FORCE_CANONICAL = 1
+PLAN_CANONICAL_INPUTS = 2     # the caller promises inputs in [0, q): include/tinyntt.h TN_PLAN_CANONICAL_INPUTS
 
 # Every symbol include/tinyntt.h declares (tests check the built library exports them all).
 EXPORTED_SYMBOLS = (
