@@ -105,9 +105,48 @@ static inline RowPlan plan_rows(size_t row_bytes, size_t batch, size_t resident)
 // barriers on all three sides (the buffer is shared with the wave-private transposes before
 // and after); a wave-local transpose only needs the compiler not to reorder it (the LDS
 // operations of one wave execute in issue order and touch that wave's private region).
+#ifndef TN_SHUFFLE_LAST
+#define TN_SHUFFLE_LAST 0        // developer A/B (profiles/r3_shuffle_ab.txt): 1 = the LAST transpose of a transform (an 8 x 8 transpose between the
+                                 // register index and the low three lane bits) through DPP lane permutes instead of LDS
+#endif
+// 8 x 8 transpose between registers and groups of 8 neighbouring lanes, without LDS: three butterfly stages; in stage b a lane
+// and its partner (lane ^ 2^b) exchange, for every register pair (r, r | 2^b), the register the other one needs.  Per pair and
+// 32-bit half: one select of what to send, the permute (quad_perm for distances 1 and 2; row_shl:4 / row_shr:4 under
+// complementary bank masks for distance 4), two selects of what to keep.
+template <int DIST> __device__ __forceinline__ u32 lane_xor(u32 v) {
+  if constexpr (DIST == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
+  else if constexpr (DIST == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+  else {
+    int r = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);                                     // row_shl:4 -> banks 0, 2 (lane i <- lane i + 4)
+    return (u32)__builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xf, 0xA, false);                                 // row_shr:4 -> banks 1, 3 (lane i <- lane i - 4)
+  }
+}
+template <typename E>
+__device__ __forceinline__ void transpose8_lanes(E (&x)[8], u32 lane) {
+  static_for<0, 3>([&](auto b_) {
+    constexpr int b = decltype(b_)::value, m = 1 << b;
+    const bool hi = (lane >> b) & 1u;
+    static_for<0, 8>([&](auto r_) {
+      constexpr int r0 = decltype(r_)::value;
+      if constexpr (!(r0 & m)) {
+        constexpr int r1 = r0 | m;
+        const E send = hi ? x[r0] : x[r1];
+        E recv;
+        if constexpr (sizeof(E) == 8) recv = ((u64)lane_xor<m>((u32)(send >> 32)) << 32) | lane_xor<m>((u32)send);
+        else recv = lane_xor<m>((u32)send);
+        x[r0] = hi ? recv : x[r0];
+        x[r1] = hi ? x[r1] : recv;
+      }
+    });
+  });
+}
+
 template <typename E, typename Cfg, int EX, int FROM, int TO>
 __device__ __forceinline__ void exchange(E (&x)[Cfg::R], u32 tau, E* lds) {
-  if constexpr (Cfg::ex_wave_local(EX)) {
+  if constexpr (TN_SHUFFLE_LAST && Cfg::LPT == 3 && EX == Cfg::PHASES - 2 && Cfg::pos(EX + 1) == 0 && Cfg::pos(EX) == Cfg::LPT) {
+    // register index <-> lane bits [0, 3): jidx(EX) = (tau >> 3) << 6 | r << 3 | (tau & 7),  jidx(EX + 1) = tau << 3 | r
+    transpose8_lanes<E>(x, tau);
+  } else if constexpr (Cfg::ex_wave_local(EX)) {
     __builtin_amdgcn_wave_barrier();
     ex_store<E, Cfg, EX, FROM>(x, tau, lds);
     __builtin_amdgcn_wave_barrier();     // lanes read what OTHER lanes of the wave wrote: loads may not move above the stores
