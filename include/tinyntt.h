@@ -232,6 +232,29 @@ tn_status tn_time_poly_mult_dev(tn_plan *plan, const void *a, const void *b, voi
 /* Name of the kernel a variant resolves to for this plan (for matching rocprof rows). */
 const char *tn_kernel_name(const tn_plan *plan, tn_variant variant);
 
+/*
+ * One call sharded over several devices.  Polynomial pairs are independent: the batch is cut into contiguous
+ * row blocks (tn_shard_rows: block sizes differ by at most one row), one block per entry; every entry has its OWN plan and stream
+ * on its device; there is no collective and no exchange.  devices == NULL: every visible device once.  A device may be listed
+ * several times (each entry still gets its own plan and stream).  The reference has no counterpart (single-threaded, one host).
+ *   tn_multi_poly_mult_host  host buffers [batch][n]: one host thread per entry runs the H2D -> kernel -> D2H pipeline of its block.
+ *   tn_multi_poly_mult_dev   operands already resident per device: a[i], b[i], c[i] hold rows[i] rows on entry i's device; the
+ *                            launches are enqueued on the entries' own streams; tn_multi_synchronize waits for all of them.
+ * Errors: the first failing entry's status; tn_multi_last_error() names the entry and carries its message.
+ */
+typedef struct tn_multi tn_multi;
+tn_status tn_shard_rows(size_t batch, int parts, int index, size_t *first_row, size_t *rows);
+tn_status tn_multi_create(tn_multi **out, uint32_t n, uint64_t q, uint64_t psi, const int *devices, int ndevices, uint32_t flags);
+tn_status tn_multi_destroy(tn_multi *m);
+int tn_multi_size(const tn_multi *m);
+tn_plan *tn_multi_plan(tn_multi *m, int index);   /* entry index's plan (owned by m) */
+int tn_multi_device(const tn_multi *m, int index);
+tn_status tn_multi_poly_mult_host(tn_multi *m, const void *a, const void *b, void *c, size_t batch, tn_variant variant);
+tn_status tn_multi_poly_mult_dev(tn_multi *m, const void *const *a, const void *const *b, void *const *c, const size_t *rows,
+                                 tn_variant variant);
+tn_status tn_multi_synchronize(tn_multi *m);
+const char *tn_multi_last_error(void);
+
 const char *tn_last_error(void);
 const char *tn_status_string(tn_status s);
 int tn_version(void);

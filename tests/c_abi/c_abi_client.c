@@ -39,6 +39,25 @@ int main(void) {
     for (int k = 0; k < N; ++k) if (c[k] != ref[k]) return 1;
     if (tn_poly_mult_host(plan, a, b, a, 1, TN_VARIANT_AUTO) != TN_EINVAL) return 1;     /* aliasing is rejected */
     tn_plan_destroy(plan);
+
+    /* the same product through the multi-device entry points: two entries (both on device 0 here), 5 rows split 3 + 2 */
+    {
+        enum { ROWS = 5 };
+        static uint32_t ma[ROWS][N], mb[ROWS][N], mc[ROWS][N];
+        tn_multi *m = NULL;
+        const int devs[2] = {0, 0};
+        size_t first = 0, rows = 0;
+        if (tn_shard_rows(ROWS, 2, 1, &first, &rows) != TN_OK || first != 3 || rows != 2) return 1;
+        if (tn_multi_create(&m, N, Q, PSI, devs, 2, TN_PLAN_DEFAULT) != TN_OK) { fprintf(stderr, "%s\n", tn_multi_last_error()); return 1; }
+        if (tn_multi_size(m) != 2 || tn_multi_device(m, 1) != 0 || !tn_multi_plan(m, 1)) return 1;
+        for (int r = 0; r < ROWS; ++r)
+            for (int i = 0; i < N; ++i) { ma[r][i] = a[(i + r) % N]; mb[r][i] = b[i]; }
+        if (tn_multi_poly_mult_host(m, ma, mb, mc, ROWS, TN_VARIANT_AUTO) != TN_OK) { fprintf(stderr, "%s\n", tn_multi_last_error()); return 1; }
+        for (int k = 0; k < N; ++k) if (mc[0][k] != ref[k]) { fprintf(stderr, "multi mismatch at %d\n", k); return 1; }
+        if (tn_poly_mult_host(tn_multi_plan(m, 0), ma[4], mb[4], c, 1, TN_VARIANT_CG) != TN_OK) return 1;   /* last row again, one plan */
+        for (int k = 0; k < N; ++k) if (mc[4][k] != c[k]) return 1;
+        tn_multi_destroy(m);
+    }
     printf("c abi ok (version %d)\n", tn_version());
     return 0;
 }

@@ -273,6 +273,45 @@ def test_general_plans_follow_the_reference_for_any_psi_and_modulus(eng, oracle)
         g.export_table("psi_brv")
 
 
+def test_multi_device_entry_points_with_two_entries_on_one_gpu(eng, oracle):
+    """tn_multi_*: one host call sharded over several device entries, each with its own plan and stream, no collective
+    (SURVEY.md §8e).  A one-GPU box lists device 0 twice (and three times with an uneven batch): every row must equal the oracle,
+    and the device-resident form must enqueue on both entries' streams."""
+    import torch
+    n, q, psi = PARAMS["P4096_60"]
+    rng = np.random.default_rng(21)
+    for entries, batch in ((2, 64), (3, 101), (2, 1)):
+        mp = eng.MultiPlan(n, q, psi, devices=[0] * entries)
+        assert mp.size == entries and mp.devices == [0] * entries
+        spans = [mp.shard(batch, i) for i in range(entries)]
+        assert sum(r for _, r in spans) == batch and spans[0][0] == 0
+        a = rng.integers(0, q, (batch, n), dtype=np.uint64); b = rng.integers(0, q, (batch, n), dtype=np.uint64)
+        ref = oracle.poly_mult(a, b, q, psi)
+        assert np.array_equal(mp.poly_mult(a, b), ref)
+        assert np.array_equal(mp.poly_mult(a, b, variant="cg8"), ref)
+        # device-resident form: per-entry pointers, enqueue on each entry's own stream, then tn_multi_synchronize
+        lib = mp._lib
+        ta = [torch.from_numpy(a[f:f + r].view(np.int64)).to("cuda:0") for f, r in spans]
+        tb = [torch.from_numpy(b[f:f + r].view(np.int64)).to("cuda:0") for f, r in spans]
+        tc = [torch.empty_like(t) for t in ta]
+        torch.cuda.synchronize()
+        import ctypes
+        vp = ctypes.c_void_p
+        pa = (vp * entries)(*[t.data_ptr() if t.numel() else None for t in ta])
+        pb = (vp * entries)(*[t.data_ptr() if t.numel() else None for t in tb])
+        pc = (vp * entries)(*[t.data_ptr() if t.numel() else None for t in tc])
+        rows = (ctypes.c_size_t * entries)(*[r for _, r in spans])
+        assert lib.tn_multi_poly_mult_dev(mp._h, pa, pb, pc, rows, 0) == eng.TN_OK, lib.tn_multi_last_error()
+        assert lib.tn_multi_synchronize(mp._h) == eng.TN_OK
+        got = np.concatenate([t.cpu().numpy().view(np.uint64) for t in tc if t.numel()])
+        assert np.array_equal(got, ref)
+        mp.close()
+    with pytest.raises(eng.TinyNttError, match="psi"):
+        eng.MultiPlan(n, q, psi + 1, devices=[0, 0])
+    with pytest.raises(eng.TinyNttError):
+        eng.MultiPlan(n, q, psi, devices=[0, 99])
+
+
 def test_two_host_threads_share_one_plan(eng, oracle):
     """*_host entry points use the plan's staging buffers, streams and events: they take a per-plan lock, so two host
     threads calling into ONE plan (with different batch sizes, which regrows the staging scratch) get correct results."""

@@ -35,7 +35,7 @@ def test_build_id_names_the_sources_the_library_was_built_from():
     build they belong to, so a library older than its sources (or an id older than the kernels) must not go unnoticed."""
     import hashlib
     d = os.path.join(ROOT, "tiny_ntt_amd", "csrc")
-    files = ["kernels.hip", "cg_part.hip", "capi.cpp", "modarith.h", "fused_core.h", "cg_core.h", "cg_kernel_impl.h", "dev_addr.h", "plan.h",
+    files = ["kernels.hip", "cg_part.hip", "capi.cpp", "multi.cpp", "modarith.h", "fused_core.h", "cg_core.h", "cg_kernel_impl.h", "dev_addr.h", "plan.h",
              "plan_tables.h", "../../include/tinyntt.h"]        # the order of csrc/Makefile: BUILD_ID
     h = hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in files)).hexdigest()[:16]
     assert engine.build_id() == h, "tiny_ntt_amd/lib/libtinyntt.so is stale: run make -C tiny_ntt_amd/csrc"
@@ -151,6 +151,22 @@ def test_shard_rows_partition():
             for (s0, c0), (s1, _) in zip(spans, spans[1:]):
                 assert s0 + c0 == s1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_c_abi_shard_rows_matches_the_python_split():
+    """tn_shard_rows (the split tn_multi_* uses) = dist.shard_rows (the split bench.py uses): contiguous blocks covering the batch
+    exactly once, sizes differing by at most one row.  Pure host arithmetic: no device needed."""
+    from tiny_ntt_amd import dist
+    lib = engine.load_library()
+    for batch in (0, 1, 7, 8, 65536, 1048576, 1000003):
+        for parts in (1, 2, 3, 4, 8):
+            for i in range(parts):
+                f, r = ctypes.c_size_t(), ctypes.c_size_t()
+                assert lib.tn_shard_rows(batch, parts, i, ctypes.byref(f), ctypes.byref(r)) == engine.TN_OK
+                assert (f.value, r.value) == dist.shard_rows(batch, parts, i)
+    f, r = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.tn_shard_rows(8, 0, 0, ctypes.byref(f), ctypes.byref(r)) == engine.TN_EINVAL
+    assert lib.tn_shard_rows(8, 2, 2, ctypes.byref(f), ctypes.byref(r)) == engine.TN_EINVAL
 
 
 def test_host_rows_take_integers_mod_q_and_refuse_floats():

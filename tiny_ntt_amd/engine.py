@@ -43,6 +43,8 @@ EXPORTED_SYMBOLS = (
     "tn_twisted_ntt_forward_host", "tn_schoolbook_host",
     "tn_fill_lcg_dev", "tn_checksum_rows_dev", "tn_plan_synchronize", "tn_time_poly_mult_dev",
     "tn_kernel_name", "tn_last_error", "tn_status_string", "tn_version", "tn_build_id",
+    "tn_shard_rows", "tn_multi_create", "tn_multi_destroy", "tn_multi_size", "tn_multi_plan", "tn_multi_device",
+    "tn_multi_poly_mult_host", "tn_multi_poly_mult_dev", "tn_multi_synchronize", "tn_multi_last_error",
 )
 
 
@@ -107,6 +109,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.tn_status_string.restype = ctypes.c_char_p
     lib.tn_version.restype = ci
     lib.tn_build_id.restype = ctypes.c_char_p
+    lib.tn_shard_rows.argtypes = [sz, ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.tn_multi_create.argtypes = [ctypes.POINTER(vp), u32, u64, u64, ctypes.POINTER(ci), ci, u32]
+    lib.tn_multi_destroy.argtypes = [vp]
+    lib.tn_multi_size.argtypes = [vp]
+    lib.tn_multi_plan.argtypes = [vp, ci]; lib.tn_multi_plan.restype = vp
+    lib.tn_multi_device.argtypes = [vp, ci]
+    lib.tn_multi_poly_mult_host.argtypes = [vp, vp, vp, vp, sz, ci]
+    lib.tn_multi_poly_mult_dev.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz), ci]
+    lib.tn_multi_synchronize.argtypes = [vp]
+    lib.tn_multi_last_error.restype = ctypes.c_char_p
     if path is None:
         _lib = lib
     return lib
@@ -401,6 +413,55 @@ class Plan:
         import torch
         h = self._host_rows(arr, "arr")
         return torch.from_numpy(h.view(np.int32 if self.elem_bytes == 4 else np.int64)).to(f"cuda:{self.device}")
+
+
+class MultiPlan:
+    """tn_multi_*: one host call sharded over several devices in contiguous row blocks, each entry with its own plan and stream
+    (no collective).  devices=None: every visible device; a device may be listed several times."""
+
+    def __init__(self, n: int, q: int, psi: int, devices=None, flags: int = 0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices) if devices is not None else None
+        st = self._lib.tn_multi_create(ctypes.byref(self._h), int(n), int(q), int(psi) % int(q), arr, len(devices) if devices is not None else 0, int(flags))
+        if st != TN_OK:
+            msg = self._lib.tn_multi_last_error().decode()
+            if st == TN_EBADLEN:
+                raise ValueError(msg)
+            raise TinyNttError(st, msg)
+        self.n, self.q, self.psi = int(n), int(q), int(psi) % int(q)
+        self.size = int(self._lib.tn_multi_size(self._h))
+        self.devices = [int(self._lib.tn_multi_device(self._h, i)) for i in range(self.size)]
+        self.elem_bytes = int(self._lib.tn_plan_elem_bytes(self._lib.tn_multi_plan(self._h, 0)))
+        self.dtype = np.uint32 if self.elem_bytes == 4 else np.uint64
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tn_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, batch: int, index: int):
+        """(first_row, rows) of entry `index` (tn_shard_rows)."""
+        f, r = ctypes.c_size_t(), ctypes.c_size_t()
+        _check(self._lib, self._lib.tn_shard_rows(int(batch), self.size, int(index), ctypes.byref(f), ctypes.byref(r)))
+        return int(f.value), int(r.value)
+
+    def poly_mult(self, a, b, variant="auto"):
+        """Host arrays [batch, n] -> [batch, n]: tn_multi_poly_mult_host."""
+        ha = np.ascontiguousarray(a, dtype=self.dtype); hb = np.ascontiguousarray(b, dtype=self.dtype)
+        if ha.ndim != 2 or ha.shape != hb.shape or ha.shape[1] != self.n:
+            raise ValueError(f"Expected {self.n} coefficients")
+        hc = np.empty_like(ha)
+        st = self._lib.tn_multi_poly_mult_host(self._h, ha.ctypes.data, hb.ctypes.data, hc.ctypes.data, ha.shape[0], _variant(variant))
+        if st != TN_OK:
+            raise TinyNttError(st, self._lib.tn_multi_last_error().decode())
+        return hc
 
 
 _plan_cache = {}

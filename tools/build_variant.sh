@@ -15,7 +15,8 @@ $HIPCC $FLAGS "$@" -c kernels.hip -o ../lib/var_$NAME/kernels.o & pids+=($!)
 $HIPCC $FLAGS "$@" -x hip -c capi.cpp -o ../lib/var_$NAME/capi.o & pids+=($!)
 for k in $PARTS; do $HIPCC $FLAGS "$@" -DTN_CG_PART=$k -c cg_part.hip -o ../lib/var_$NAME/cg_part$k.o & pids+=($!); done
 for p in "${pids[@]}"; do wait $p; done
-OBJS="../lib/var_$NAME/kernels.o ../lib/var_$NAME/capi.o"
+[ -f ../lib/multi.o ] || make ../lib/multi.o
+OBJS="../lib/var_$NAME/kernels.o ../lib/var_$NAME/capi.o ../lib/multi.o"
 for k in 0 1 2 3 4 5 6; do
   if [ -f ../lib/var_$NAME/cg_part$k.o ]; then OBJS="$OBJS ../lib/var_$NAME/cg_part$k.o"; else [ -f ../lib/cg_part$k.o ] || make ../lib/cg_part$k.o; OBJS="$OBJS ../lib/cg_part$k.o"; fi
 done
