@@ -276,9 +276,11 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=None, help="rows of ONE global batch split over the ranks, strong scaling")
     ap.add_argument("--variant", default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency", action="store_true", help="N=1: skip the small-batch latency block")
-    ap.add_argument("--no-curve-point", action="store_true",
-                    help="N=1, cfg3: skip the strong-scaling reference point (the whole 2^20-pair batch of BASELINE configs[3] on this GPU)")
+    # both off by default: they launch the SAME kernel on other batch sizes, and the default command's rocprofv3 --kernel-trace --stats
+    # summary must show that kernel's average launch duration for the bench workload alone (profiles/r3_f_kernel_stats.csv)
+    ap.add_argument("--latency", action="store_true", help="N=1: add the small-batch latency block (1 / 16 / 256 pairs device-resident, 1 pair host-buffer)")
+    ap.add_argument("--strong-point", action="store_true",
+                    help="N=1, cfg3: add the N = 1 point of the strong-scaling curve (the whole 2^20-pair batch of BASELINE configs[3] on this GPU)")
     ap.add_argument("--allow-gloo", action="store_true",
                     help="N>1: if the RCCL control plane cannot come up, run the barrier / max-reduce over gloo instead of failing")
     ap.add_argument("--scatter-gather", type=int, default=0, metavar="ROWS",
@@ -446,9 +448,9 @@ def main():
         base, oracle_rows, latency, curve = None, 0, None, None
         if not (args.no_cpu_baseline or world > 1):          # the CPU leg, part 1: the oracle as checker on sampled rows
             oracle_rows = oracle_check(plan, a, b, c, cfg)
-        if world == 1 and not args.no_latency:
+        if world == 1 and args.latency:
             latency = latency_block(plan, a, b, c, args.variant)
-        if world == 1 and args.config == "cfg3" and not args.no_curve_point and sp["global_batch"] != cfg["global_batch"]:
+        if world == 1 and args.config == "cfg3" and args.strong_point:
             # the N = 1 point of the strong-scaling curve (BASELINE configs[3]: ONE batch of 2^20 pairs over 1/2/4/8 GPUs): the whole
             # batch on this GPU (96 GiB of a, b, c), same kernel, a few launches; N > 1 lines divide THIS batch
             try:
@@ -460,7 +462,7 @@ def main():
                 ms = plan.time_poly_mult(A, B, C, 5, args.variant)
                 ok = int(plan.checksum_rows(C[:1], stream="plan")[0]) == cfg["checksum_row0"]
                 curve = {"global_batch": gb, "n_gpus": 1, "value": round(gb / (ms * 1e-3), 1), "ms_per_step": round(ms, 3),
-                         "row0_matches_reference": ok, "command": f"python bench.py --gpus 1 --global-batch {gb}"}
+                         "row0_matches_reference": ok, "command": f"python bench.py --gpus 1 --global-batch {gb}  (or: python bench.py --strong-point)"}
                 del A, B, C
                 torch.cuda.empty_cache()
             except Exception as e:                                 # e.g. a smaller GPU: the point is optional

@@ -24,7 +24,7 @@ def run_bench(*args, env=None):
 
 
 def test_single_gpu_line_small_workload():
-    j = run_bench("--steps", "3", "--warmup", "1", "--rows", "2048", "--no-cpu-baseline")
+    j = run_bench("--steps", "3", "--warmup", "1", "--rows", "2048", "--no-cpu-baseline", "--latency")
     assert j["n_gpus"] == 1 and j["dtype"] == "u64" and j["unit"] == "poly-mults/s" and j["higher_is_better"] is True
     assert j["control_plane"] == "none" and j["scaling"] == "weak"
     p = j["parity"]
@@ -33,6 +33,8 @@ def test_single_gpu_line_small_workload():
     assert r["bound"] == "hbm" and r["algorithmic_bytes_per_launch"] == 2048 * 98304 and 0 < r["frac"] < 1
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
     assert j["config"]["lib_build_id"] not in ("", "unknown")
+    assert j["per_rank"]["rows"] == [2048] and set(j["latency"]["device_resident_us"]) == {"1", "16", "256"} and j["latency"]["host_buffer_us"]["1"] > 0
+    assert j["strong_scaling_n1_point"] is None          # only with --strong-point
 
 
 def test_cfg2_line_with_reference_cpu_baseline():
@@ -53,3 +55,6 @@ def test_two_ranks_without_launcher_strong_split_over_gloo():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["control_plane"] == "gloo" and j["control_plane_ranks"] == 2
     assert j["config"]["global_batch"] == 3000 and j["config"]["rows_per_gpu"] == 1500
     assert j["parity"]["bit_exact"] is True
+    # a straggler would show in the per-rank lists; the N = 1 blocks stay off an N > 1 line
+    assert j["per_rank"]["rows"] == [1500, 1500] and len(j["per_rank"]["kernel_ms"]) == 2 and min(j["per_rank"]["kernel_ms"]) > 0
+    assert j["latency"] is None and j["strong_scaling_n1_point"] is None and j["spinup_launches"] == 40
