@@ -233,18 +233,22 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
   std::vector<E> img(M::span(n) + 4, (E)0xDEADBEEFu);
   std::vector<Tw> ldstab(n / 2 + 1);
   auto stage_table = [&](const std::vector<Tw>& g) { for (u32 j = 0; j <= n / 2; ++j) ldstab[cg_twmap<GROUP, LAYOUT>(j, big)] = g[j]; };
-  struct Regs { E x[R]; };
+  struct Regs { E x[R]; Tw w0[GROUP]; };
+  constexpr bool CAN_MERGE = TN_CG_MERGE_TWIST && A::LAZY;           // cg_kernel_impl.h: the twist of stage 1's right inputs rides the butterflies
 
   // x: registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list) -> natural order (x[e] = output ls + e TP)
-  auto transform = [&](std::vector<Regs>& x, bool inverse, bool rev, u64* tr) {
+  auto transform = [&](std::vector<Regs>& x, bool inverse, bool rev, u64* tr, bool merged = false) {
     const Tw* glob = inverse ? inv.data() : fwd.data();
     auto run_first = [&](auto nst_) {
       constexpr int NST = decltype(nst_)::value;
       for (u32 ls = 0; ls < TP; ++ls) {
         const u32 T = h_brv(ls, logn - L);
-        cg_trip<E, GROUP, AM, NST, false>(x[ls].x, ar,
-          [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1))]; },
-          [&](auto j_) { if (tr) for (u32 e = 0; e < (u32)R; ++e) tr[(size_t)decltype(j_)::value * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[ls].x[e]; });
+        auto tw = [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1))]; };
+        auto after = [&](auto j_) { if (tr) for (u32 e = 0; e < (u32)R; ++e) tr[(size_t)decltype(j_)::value * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[ls].x[e]; };
+        if constexpr (CAN_MERGE) {
+          if (merged) cg_trip<E, GROUP, AM, NST, false, 0, true>(x[ls].x, ar, tw, after, [&](auto g_) { return x[ls].w0[decltype(g_)::value]; });
+          else cg_trip<E, GROUP, AM, NST, false>(x[ls].x, ar, tw, after);
+        } else cg_trip<E, GROUP, AM, NST, false>(x[ls].x, ar, tw, after);
         if (ntrips > 1) for (u32 e = 0; e < (u32)R; ++e) img[M::at(Ge::pos(logn, NST, T, e))] = x[ls].x[e];
       }
     };
@@ -275,17 +279,19 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
       if (trip + 1 < ntrips) for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) img[M::at(Ge::pos(logn, L, ls, e))] = x[ls].x[e];
     }
   };
-  auto load = [&](std::vector<Regs>& x, const u64* in, const Tw* twist) {
+  auto load = [&](std::vector<Regs>& x, const u64* in, const Tw* twist) {       // returns: the first stage is the merged one
     for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) {
       const u32 i = ls + e * TP;
-      x[ls].x[Ge::brvL(e)] = twist ? A::in_mul((E)in[i], twist[i], ar) : A::in_red((E)in[i], ar);
+      if (twist && CAN_MERGE && e >= (u32)GROUP) { x[ls].x[Ge::brvL(e)] = (E)in[i]; x[ls].w0[Ge::brvL(e) >> 1] = twist[i]; }
+      else x[ls].x[Ge::brvL(e)] = twist ? A::in_mul((E)in[i], twist[i], ar) : A::in_red((E)in[i], ar);
     }
+    return twist && CAN_MERGE;
   };
   std::vector<Regs> xa(TP), xb(TP);
   if (mode == 0 || mode == 3) {
     stage_table(fwd);
-    load(xa, a, mode == 3 ? psi_pow.data() : nullptr);
-    transform(xa, false, false, trace);
+    const bool m = load(xa, a, mode == 3 ? psi_pow.data() : nullptr);
+    transform(xa, false, false, trace, m);
     for (u32 ls = 0; ls < TP; ++ls) for (u32 e = 0; e < (u32)R; ++e) out[ls + e * TP] = A::out_canon(xa[ls].x[e], ar);
   } else if (mode == 1) {
     stage_table(inv);
@@ -296,8 +302,8 @@ int cgm_emu(const HostTables& t, int mode, int flags, const u64* a, const u64* b
     const Tw* twist = mode == 4 ? nullptr : psi_pow.data();
     const bool rev = !(flags & 2);
     stage_table(fwd);
-    load(xa, a, twist); transform(xa, false, false, nullptr);
-    load(xb, b, twist); transform(xb, false, false, nullptr);
+    const bool ma = load(xa, a, twist); transform(xa, false, false, nullptr, ma);
+    const bool mb = load(xb, b, twist); transform(xb, false, false, nullptr, mb);
     for (u32 ls = 0; ls < TP; ++ls) {
       E c[R];
       for (u32 e = 0; e < (u32)R; ++e) c[e] = A::pointwise(xa[ls].x[e], xb[ls].x[e], ar);

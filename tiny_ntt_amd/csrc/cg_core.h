@@ -23,6 +23,9 @@
 #pragma once
 #include "fused_core.h"
 
+#ifndef TN_CG_MERGE_TWIST
+#define TN_CG_MERGE_TWIST 1      // lazy arithmetic: the twist of the right inputs rides the stage-1 butterflies (CgArith::bf_first)
+#endif
 #ifndef TN_CG_FENCE
 #define TN_CG_FENCE 2            // butterflies between two vector-ALU scheduling fences of a stage (0: none)
 #endif
@@ -151,6 +154,18 @@ template <typename E, int AM> struct CgArith {
       dif = left >= t ? (E)(left - t) : (E)(left + (ar.q - t));      // :59
     }
   }
+  // Stage 1 of a TWISTED transform, lazy modes only (TN_CG_MERGE_TWIST): every twiddle of stage 1 is omega^0 = 1 (cg_ntt.py:51,:54
+  // with i < k), so the butterfly's product 1 * a'[2i+1] can BE the twist multiplication a[j + n/2] * psi^(j + n/2) of its
+  // right input (:82-83): w = that record, the right input arrives as the raw word (any 64-bit value), the left input twisted as
+  // before.  Same residues, half the twist multiplications.  t' < tmax(2^64) (slightly above 6 * 2^k), hence K = 7; the outputs
+  // (below 13.01 * 2^k) are admissible inputs of stage 2 in both lazy schedules (h_cg_lazy_ok, h_cg_sched_ok replay this).
+  TN_HD static void bf_first(E left, E right_raw, Tw w, const Arith<E>& ar, E& sum, E& dif) {
+    static_assert(LAZY, "merged twist: lazy arithmetic only");
+    const u64 u = SCHED ? (u64)left : fold(left, ar.k, ar.fold_c);
+    const u64 x = mul_sp_acc(u, right_raw, w, ar.sk);
+    dif = ((u << 1) + ar.qmul[7]) - x;
+    sum = x;
+  }
   // A^[i] * B^[i] (cg_ntt.py:88): canonical Barrett product of canonical values, or the fused kernels' lazy product (< 2q)
   TN_HD static E pointwise(E a, E b, const Arith<E>& ar) {
     if constexpr (LAZY) return pointwise_lazy(a, b, ar);
@@ -173,19 +188,22 @@ template <typename E, int AM> struct CgArith {
 //             omega^-i = -omega^(n/2 - i)), so the two outputs change places
 //   after(j)  called after stage j with the registers in their new places (per-stage trace)
 //   S0PAR     parity of the number of stages done before this trip (the scheduled arithmetic folds on even stages)
-template <typename E, int GROUP, int AM, int NST, bool SWAP, int S0PAR = 0, typename TW, typename AFTER>
-TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after) {
+//   MERGE0    stage 0 is the merged twist + butterfly (CgArith::bf_first): w0(g) = the twist record of butterfly g's right input
+struct CgNoW0 { template <typename G_> TN_HD int operator()(G_) const { return 0; } };
+template <typename E, int GROUP, int AM, int NST, bool SWAP, int S0PAR = 0, bool MERGE0 = false, typename TW, typename AFTER, typename W0 = CgNoW0>
+TN_HD void cg_trip(E (&x)[2 * GROUP], const Arith<E>& ar, TW&& tw, AFTER&& after, W0&& w0 = W0()) {
   constexpr int G = GROUP, L = CgGeom<G>::L;
   typedef typename TwOf<E>::type Tw;
   static_for<0, NST>([&](auto j_) {
     constexpr int j = decltype(j_)::value;
     Tw w[1 << j];
-    static_for<0, (1 << j)>([&](auto h_) { w[decltype(h_)::value] = tw(j_, h_); });
+    if constexpr (!(MERGE0 && j == 0)) static_for<0, (1 << j)>([&](auto h_) { w[decltype(h_)::value] = tw(j_, h_); });
     E z[2 * G];
     static_for<0, G>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
       constexpr bool EVEN = ((S0PAR + j + 1) & 1) == 0;                 // stage number s0 + j + 1 (cg_ntt.py:49)
-      if constexpr (SWAP) CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
+      if constexpr (MERGE0 && j == 0) CgArith<E, AM>::bf_first(x[2 * g], x[2 * g + 1], w0(g_), ar, z[g], z[G + g]);
+      else if constexpr (SWAP) CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[G + g], z[g]);
       else CgArith<E, AM>::template bf<EVEN>(x[2 * g], x[2 * g + 1], w[g >> (L - 1 - j)], ar, z[g], z[G + g]);
       if constexpr (TN_CG_FENCE > 0 && ((g + 1) % (TN_CG_FENCE > 0 ? TN_CG_FENCE : 1)) == 0 && g + 1 < G) sched_fence_valu();   // bounds the butterflies in flight (live temporaries)
     });

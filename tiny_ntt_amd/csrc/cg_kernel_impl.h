@@ -109,7 +109,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // x: one lane-step's registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list, cg_ntt.py:39)
   // -> natural order (x[e] = element ls + e TP of the transform).  glob: the table in global memory for the trips whose
   // twiddles are wave-uniform; the LDS table is read directly, or backwards with the outputs swapped (rev).
-  auto transform = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) TN_INL {
+  // The first trip of a transform (registers only).  merge_: stage 1 is the merged twist + butterfly (lazy arithmetic, twisted
+  // transforms): w0[it][g] = the twist record of butterfly g's right input, which arrives untwisted (CgArith::bf_first).
+  auto first_trip = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, E* tr, auto merge_, const TwRaw (&w0)[ITERS][GROUP]) TN_INL {
+    constexpr bool MERGE = decltype(merge_)::value;
     // opaque zero / thread index: keep the (loop-invariant) uniform twiddle loads and per-column LDS addresses of a transform
     // inside the persistent row loop instead of in registers across it (see polymul_fused_kernel)
     const u32 zero = opaque_zero();
@@ -120,16 +123,17 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       const u32 T = logn > (u32)L ? __brev(lsi) >> (32 - (logn - L)) : 0u;      // first trip: thread t plays lane-step brv(t) (cg_core.h)
       auto first = [&](auto nst_) TN_INL {
         constexpr int NST = decltype(nst_)::value;
-        cg_trip<E, GROUP, AM, NST, false>(x[it], ar,
+        cg_trip<E, GROUP, AM, NST, false, 0, MERGE>(x[it], ar,
           [&](auto j_, auto h_) { return glob[(u32)decltype(h_)::value * (n >> (decltype(j_)::value + 1)) + zero]; },
           [&](auto j_) {
-            if constexpr (AM != CGA_SPLIT_LAZY) {
+            if constexpr (!A::LAZY) {
               if (tr) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) tr[(size_t)decltype(j_)::value * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[it][e];
               }
             }
-          });
+          },
+          [&](auto g_) { return tw_pack(w0[it][decltype(g_)::value]); });
       };
       if (r1 == (u32)L) first(std::integral_constant<int, L>());
       else if constexpr (L >= 2) {
@@ -140,6 +144,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         }
       }
     }
+  };
+  // ... and the rest of it: the transposes and the later trips.
+  auto rest = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) TN_INL {
+    const u32 zero = opaque_zero();
     // Two workgroup barriers per LDS transpose, both around the WRITE: one before it (every wave has read what the image
     // held: the previous trip's columns, or the previous transform's) and one after it (the columns are in the image).
     // A wave's reads are followed by its arithmetic, not by a barrier, so no wave waits at a barrier for LDS latency.
@@ -180,7 +188,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         if (!is_live(it)) continue;
         const u32 T = opaque_copy(lane_step(it)), base0 = cg_tw_base0<GROUP>(logn, s0, T);
         auto after = [&](auto j_) TN_INL {
-          if constexpr (AM != CGA_SPLIT_LAZY) {
+          if constexpr (!A::LAZY) {
             if (tr) {
 #pragma unroll
               for (int e = 0; e < R; ++e) tr[(size_t)(s0 + decltype(j_)::value) * n + Ge::pos(logn, decltype(j_)::value + 1, T, e)] = x[it][e];
@@ -230,6 +238,14 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     }
     if constexpr (PINGPONG) pp ^= img_elems;                         // the next transform starts in the image this one did not use last
   };
+  // x: one lane-step's registers in bit-reversed order (x[brvL(e')] = element ls + e' TP of the input list, cg_ntt.py:39)
+  // -> natural order (x[e] = element ls + e TP of the transform).  glob: the table in global memory for the trips whose
+  // twiddles are wave-uniform; the LDS table is read directly, or backwards with the outputs swapped (rev).
+  const TwRaw no_w0[ITERS][GROUP] = {};
+  auto transform = [&](E (&x)[ITERS][R], const Tw* __restrict__ glob, bool rev, E* tr) TN_INL {
+    first_trip(x, glob, tr, std::integral_constant<bool, false>(), no_w0);
+    rest(x, glob, rev, tr);
+  };
 
   // Operand and table accesses are "uniform base (row, column e: scalar unit) + the lane-step as a 32-bit offset"; the
   // lane-step is taken through opaque_copy per use so that base + offset is not a loop invariant of the row loop
@@ -267,8 +283,11 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       });
     }
   };
-  // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order
-  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], auto twisted_, const Tw* tab) TN_INL {
+  // y[brvL(e)] = x[e] * psi^(ls + e TP)  (cg_ntt.py:82-83), or x[e] mod q — in the first trip's register order.
+  // MERGED (lazy arithmetic, twisted): only the LEFT inputs of stage 1 (columns e < GROUP) are twisted here; the right inputs
+  // (columns e >= GROUP = the other half of the polynomial) stay raw and their records go to w0 for CgArith::bf_first.
+  constexpr bool CAN_MERGE = TN_CG_MERGE_TWIST && A::LAZY;
+  auto enter = [&](E (&y)[ITERS][R], const E (&x)[ITERS][R], auto twisted_, const Tw* tab, TwRaw (&w0)[ITERS][GROUP]) TN_INL {
     constexpr bool TWISTED = decltype(twisted_)::value;
     TwRaw rec[ITERS][R];
     if constexpr (TWISTED) fetch_records(rec, tab);
@@ -277,13 +296,15 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       if (!is_live(it)) continue;
       static_for<0, R>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
-        if constexpr (TWISTED) y[it][Ge::brvL(e)] = A::in_mul(x[it][e], tw_pack(rec[it][e]), ar);
+        if constexpr (TWISTED && CAN_MERGE && e >= GROUP) { y[it][Ge::brvL(e)] = x[it][e]; w0[it][Ge::brvL(e) >> 1] = rec[it][e]; }
+        else if constexpr (TWISTED) y[it][Ge::brvL(e)] = A::in_mul(x[it][e], tw_pack(rec[it][e]), ar);
         else y[it][Ge::brvL(e)] = A::in_red(x[it][e], ar);
       });
     }
   };
   // the same for both operands of a product on ONE fetch of the twist records (both rows already in registers)
-  auto enter2 = [&](E (&ya)[ITERS][R], const E (&xa_)[ITERS][R], E (&yb)[ITERS][R], const E (&xb_)[ITERS][R], auto twisted_, const Tw* tab) TN_INL {
+  auto enter2 = [&](E (&ya)[ITERS][R], const E (&xa_)[ITERS][R], E (&yb)[ITERS][R], const E (&xb_)[ITERS][R], auto twisted_, const Tw* tab,
+                    TwRaw (&w0)[ITERS][GROUP]) TN_INL {
     constexpr bool TWISTED = decltype(twisted_)::value;
     TwRaw rec[ITERS][R];
     if constexpr (TWISTED) fetch_records(rec, tab);
@@ -292,7 +313,9 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       if (!is_live(it)) continue;
       static_for<0, R>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
-        if constexpr (TWISTED) {
+        if constexpr (TWISTED && CAN_MERGE && e >= GROUP) {
+          ya[it][Ge::brvL(e)] = xa_[it][e]; yb[it][Ge::brvL(e)] = xb_[it][e]; w0[it][Ge::brvL(e) >> 1] = rec[it][e];
+        } else if constexpr (TWISTED) {
           const Tw w = tw_pack(rec[it][e]);
           ya[it][Ge::brvL(e)] = A::in_mul(xa_[it][e], w, ar);
           yb[it][Ge::brvL(e)] = A::in_mul(xb_[it][e], w, ar);
@@ -420,12 +443,16 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     E xb[ITERS][R];
     if constexpr (AHEAD) {
       TN_STAMP(7);
-      enter2(xa, xn, xb, xm, twisted_, tw_in);                     // :82-83
+      TwRaw w0[ITERS][GROUP];
+      enter2(xa, xn, xb, xm, twisted_, tw_in, w0);                 // :82-83
       if constexpr (DEFER) { sched_fence(); emit_row(vprev, prev_row, zero); sched_fence(); }
       TN_STAMP(0);
-      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
+      constexpr bool MERGED = TWISTED && CAN_MERGE;
+      first_trip(xa, om_fwd, nullptr, std::integral_constant<bool, MERGED>(), w0);     // both first trips on one fetch of the records
+      first_trip(xb, om_fwd, nullptr, std::integral_constant<bool, MERGED>(), w0);
+      rest(xa, om_fwd, false, nullptr);                            // :86  A^ stays in registers
       TN_STAMP(1);
-      transform(xb, om_fwd, false, nullptr);                       // :87
+      rest(xb, om_fwd, false, nullptr);                            // :87
       TN_STAMP(2);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -444,15 +471,19 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     } else {
       // vector-memory operations retire in order: b's row (HBM) is requested AFTER the twist of a has consumed its records
       // (L2), so that nothing of a's path waits for HBM; b stays in flight while a is transformed
-      enter(xa, xn, twisted_, tw_in);                              // :82
+      constexpr bool MERGED = TWISTED && CAN_MERGE;
+      TwRaw w0[ITERS][GROUP];
+      enter(xa, xn, twisted_, tw_in, w0);                          // :82
       sched_fence();
       if constexpr (DEFER) emit_row(vprev, prev_row, zero);
       load_row(xb, b, row, zero);
       sched_fence();
-      transform(xa, om_fwd, false, nullptr);                       // :86  A^ stays in registers
+      first_trip(xa, om_fwd, nullptr, std::integral_constant<bool, MERGED>(), w0);
+      rest(xa, om_fwd, false, nullptr);                            // :86  A^ stays in registers
       sched_fence();                                               // (or the scheduler requests b's twist records a whole transform early)
-      enter(xn, xb, twisted_, tw_in);                              // :83
-      transform(xn, om_fwd, false, nullptr);                       // :87
+      enter(xn, xb, twisted_, tw_in, w0);                          // :83
+      first_trip(xn, om_fwd, nullptr, std::integral_constant<bool, MERGED>(), w0);
+      rest(xn, om_fwd, false, nullptr);                            // :87
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         if (!is_live(it)) continue;
@@ -489,11 +520,21 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     else if (mode == CG_CYCLIC_POLYMUL) product_row(False(), nrow, zero, tw_in, tw_out);
     else {
       E* tr = trace ? trace + (size_t)row * logn * n : nullptr;
-      if (mode == CG_TWIST_FWD) enter(xa, xn, True(), tw_in); else enter(xa, xn, False(), tw_in);
-      sched_fence();
-      load_row(xn, a, nrow, zero);
-      if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, K1(), zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
-      else { transform(xa, om_fwd, false, tr); store_row(xa, row, K0(), zero, tw_out); }
+      TwRaw w0[ITERS][GROUP];
+      if (mode == CG_TWIST_FWD) {                                  // forward_ntt_bench: twist + cg_ntt
+        enter(xa, xn, True(), tw_in, w0);
+        sched_fence();
+        load_row(xn, a, nrow, zero);
+        first_trip(xa, om_fwd, tr, std::integral_constant<bool, CAN_MERGE>(), w0);
+        rest(xa, om_fwd, false, tr);
+        store_row(xa, row, K0(), zero, tw_out);
+      } else {
+        enter(xa, xn, False(), tw_in, w0);
+        sched_fence();
+        load_row(xn, a, nrow, zero);
+        if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, K1(), zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
+        else { transform(xa, om_fwd, false, tr); store_row(xa, row, K0(), zero, tw_out); }
+      }
     }
   }
   if constexpr (DEFER) { if (have_prev) emit_row(vprev, prev_row, 0u); }

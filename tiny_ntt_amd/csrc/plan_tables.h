@@ -165,6 +165,17 @@ inline bool h_cg_lazy_ok(int k, u64 c) {
   if (x.folded(B) > (u128)2 * x.q) x.ok = false;    // canonicalisation afterwards: fold, one conditional subtraction
   if (x.tmax(x.two64) > B) x.ok = false;            // lazy twist on load: the bare product of any word is a valid stage input
   if (B > (u128)14 * (x.q - 1)) x.ok = false;       // lazy pointwise product (pointwise_lazy): second operand below 14q, result < 2q <= B
+  // merged twist + stage-1 butterfly (CgArith::bf_first): left folded, right ANY word, K = 7; its outputs enter stage 2 (left folded again)
+  {
+    const u128 t1 = x.tmax(x.two64), k7 = (u128)7 * x.q;
+    if (k7 + 1 < t1) x.ok = false;
+    x.fits(bu - 1 + t1); x.fits(bu + k7);
+    const u128 out1 = (bu + t1 - 1) > (bu + k7) ? (bu + t1 - 1) : (bu + k7);
+    const u128 t2 = x.tmax(out1);
+    if (kq + 1 < t2) x.ok = false;                  // stage 2 still uses 6q
+    x.fits(bu - 1 + t2);
+    if (bu + t2 - 1 > B) x.ok = false;
+  }
   return x.ok;
 }
 
@@ -178,13 +189,23 @@ inline bool h_cg_sched_ok(int k, u64 c) {
   u128 b_odd = x.tmax(x.two64);                       // input bound of an odd stage: twist output (folded / pointwise inputs are smaller)
   const u128 fold_any = x.folded(x.two64);
   if (fold_any > b_odd) b_odd = fold_any;
+  // merged twist + stage-1 butterfly (CgArith::bf_first): left = the bare twist product (< tmax(2^64)), right ANY word, K = 7;
+  // its outputs are the inputs of stage 2 (even: left folded, 6q)
+  u128 out_merged = 0;
+  {
+    const u128 bl = x.tmax(x.two64), t1 = x.tmax(x.two64), k7 = (u128)7 * x.q;
+    if (k7 + 1 < t1) x.ok = false;
+    x.fits(bl - 1 + t1); x.fits(bl + k7);
+    out_merged = (bl + t1 - 1) > (bl + k7) ? (bl + t1 - 1) : (bl + k7);
+  }
   for (int it = 0; it < 4; ++it) {
     // odd stage: u raw (< b_odd), v < b_odd
     const u128 t1 = x.tmax(b_odd), k5 = (u128)5 * x.q;
     if (k5 + 1 < t1) x.ok = false;
     x.fits(b_odd - 1 + t1); x.fits(b_odd + k5);
     const u128 s1 = b_odd + t1 - 1, d1 = b_odd + k5;
-    const u128 b_even = s1 > d1 ? s1 : d1;
+    u128 b_even = s1 > d1 ? s1 : d1;
+    if (out_merged > b_even) b_even = out_merged;      // stage 2 may follow the merged first stage
     // even stage: u folded, v < b_even
     const u128 bu = x.folded(b_even), t2 = x.tmax(b_even), k6 = (u128)6 * x.q;
     if (k6 + 1 < t2) x.ok = false;
