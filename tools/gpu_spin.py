@@ -9,9 +9,10 @@ SHAPES = {"": (4096, 1152921504606830593, 431606828070683274, 65536), "p1024": (
 n, q, psi, B = SHAPES[os.environ.get("SPIN_SHAPE", "")]
 plan = engine.Plan(n, q, psi)
 a = plan.fill_lcg(B, 1, 2); b = plan.fill_lcg(B, 2, 2); c = torch.empty_like(a)
-plan.time_poly_mult(a, b, c, 3, "fused")
+V = os.environ.get("SPIN_VARIANT", "fused")           # SPIN_VARIANT=cg8_padded ...: any engine.VARIANTS name
+plan.time_poly_mult(a, b, c, 3, V)
 open(sys.argv[1], "w").write("go\n")
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
-    ms = plan.time_poly_mult(a, b, c, 500, "fused")
+    ms = plan.time_poly_mult(a, b, c, 500, V)
     print(f"spin: {ms:.3f} ms/launch", flush=True)
 os.remove(sys.argv[1])
