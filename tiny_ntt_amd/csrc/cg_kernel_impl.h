@@ -98,7 +98,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // the time spent waiting at workgroup barriers, accumulated in scalar registers and written once, at the end, to a
   // buffer of their own (the trace pointer, unused by products); no output value depends on them.
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_bar = 0, st_last = __builtin_amdgcn_s_memtime();
-  const unsigned long long st_begin = st_last;
+  const unsigned long long st_begin = st_last, st_rbegin = __builtin_amdgcn_s_memrealtime();
 #define TN_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
 #define TN_BARRIER() do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); st_bar += __builtin_amdgcn_s_memtime() - t0_; } while (0)
 #else
@@ -542,7 +542,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   if (trace && (mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL) && (threadIdx.x & 63) == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(trace) + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;
     for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
-    o[8] = st_bar; o[9] = __builtin_amdgcn_s_memtime() - st_begin; o[10] = __builtin_amdgcn_s_memrealtime(); o[11] = st_begin;
+    o[8] = st_bar; o[9] = __builtin_amdgcn_s_memtime() - st_begin; o[10] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o[11] = st_begin;      // [10]: the same interval on the constant 100 MHz clock
   }
 #endif
 }

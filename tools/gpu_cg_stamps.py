@@ -33,5 +33,7 @@ for v in variants:
         print(f"   {names[k]:32s} {m / rows_per_wave:9.0f} cycles/row  {100 * m / tot:5.1f} %")
     bar = np.median(st[:, 8])
     print(f"   {'of which: waiting at barriers':32s} {bar / rows_per_wave:9.0f} cycles/row  {100 * bar / tot:5.1f} %")
-    # in-kernel clock: s_memtime counts shader cycles, s_memrealtime 100 MHz; wave lifetime / wall time of the launch
-    print(f"   in-kernel clock ~ {tot / (ms * 1e-3) / 1e9:.3f} GHz (median wave lifetime in shader cycles / launch time by HIP events)")
+    # in-kernel clock: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz clock, both over the wave's lifetime
+    clk = np.median(st[:, 9] / np.maximum(st[:, 10], 1)) * 100e6
+    life = np.median(st[:, 10]) / 100e6
+    print(f"   in-kernel clock {clk / 1e9:.3f} GHz (s_memtime / s_memrealtime over a wave's lifetime, median); a wave lives {life * 1e3:.3f} ms of the {ms:.3f} ms launch")
