@@ -15,6 +15,12 @@
 #include "cg_core.h"
 #include "dev_addr.h"
 
+#ifndef TN_CG_DYNAMIC_ROWS
+#define TN_CG_DYNAMIC_ROWS 1     // 1: persistent workgroups take their rows from a device counter (fixed stride below TN_CG_DYNAMIC_MIN rows each)
+#endif
+#ifndef TN_CG_DYNAMIC_MIN
+#define TN_CG_DYNAMIC_MIN 8
+#endif
 #ifndef TN_CG_NT_STREAM
 #define TN_CG_NT_STREAM 1        // 1: non-temporal loads/stores for the streamed operands (keeps L2 for the tables)
 #endif
@@ -60,7 +66,7 @@ __global__ void __launch_bounds__((CgShape<E, GROUP, BIG, CTLOGN>::THREADS_MAX),
 cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>::type* __restrict__ om_fwd,
           const typename TwOf<E>::type* __restrict__ om_inv, const typename TwOf<E>::type* __restrict__ psi_pow,
           const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const typename TwOf<E>::type* __restrict__ psi_inv_pow,
-          const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* __restrict__ trace, u32 batch) {
+          const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* __restrict__ trace, u32 batch, u32* sched) {
   // (the tables are separate __restrict__ arguments so that wave-uniform twiddle loads become scalar loads: see polymul_fused_kernel)
   typedef CgGeom<GROUP> Ge;
   typedef CgMap<E, GROUP, LAYOUT> M;
@@ -84,6 +90,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   E* img = reinterpret_cast<E*>(tn_smem);
   Tw* ltab = reinterpret_cast<Tw*>(img + (PINGPONG ? 2u : 1u) * img_elems);
   u32 pp = 0;                                                     // ping-pong: element offset of the image the next transpose writes
+  u32* lds_next = reinterpret_cast<u32*>(ltab + (n >> 1) + 1);     // two slots: the row this workgroup takes after the current one (double-buffered)
   auto stage_table = [&](const Tw* __restrict__ src) TN_INL {            // omega^j (or omega^-j), j <= n/2
     for (u32 j = threadIdx.x; j <= (n >> 1); j += blockDim.x) ltab[cg_twmap<GROUP, LAYOUT>(j, big)] = src[j];
   };
@@ -393,6 +400,14 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     emit_row(v, row, zero);
   };
 
+  // Row hand-out.  sched != nullptr: rows come from a device-wide counter (one atomicAdd per row, by thread 0), as in the fused
+  // kernels: the two workgroups of a CU do not run at the same speed (the SIMD's issue arbitration favours the older wave: with
+  // equal fixed shares one workgroup finished after 1.83 ms and its neighbour ran the last 0.9 ms alone, profiles/r3_cg_stamps.txt),
+  // so the faster one simply takes more rows and the launch ends when the work does.  sched == nullptr: fixed stride gridDim.x.
+  // The index travels through LDS one row ahead of its use: while row k runs, every thread reads the index of row k+1 from one
+  // slot (written during row k-1) and thread 0 requests the index of row k+2 and writes it to the other slot; the workgroup
+  // barriers inside every row order each slot's write before its read and its read before the next write.
+  if (threadIdx.x == 0) lds_next[0] = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : blockIdx.x + gridDim.x;
   stage_table(mode == CG_NTT_INV ? om_inv : om_fwd);
   __syncthreads();
 
@@ -438,6 +453,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
 #pragma unroll
       for (int e = 0; e < R; ++e) vprev[it][e] = 0;
   }
+  u32 slot = 0, next = 0, got = 0;                                 // slot: which of the two LDS slots holds the next row's index
+  // called once per row, after the row's first table fetch has been consumed (the atomic's latency hides behind it): thread 0
+  // publishes the index of the row after `next`
+  auto publish_next = [&]() TN_INL { if (threadIdx.x == 0) lds_next[slot ^ 1u] = sched ? gridDim.x + got : next + gridDim.x; };
   auto product_row = [&](auto twisted_, u32 nrow, u32 zero, const Tw* tw_in, const Tw* tw_out) TN_INL {
     constexpr bool TWISTED = decltype(twisted_)::value;
     E xb[ITERS][R];
@@ -445,6 +464,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       TN_STAMP(7);
       TwRaw w0[ITERS][GROUP];
       enter2(xa, xn, xb, xm, twisted_, tw_in, w0);                 // :82-83
+      publish_next();
       if constexpr (DEFER) { sched_fence(); emit_row(vprev, prev_row, zero); sched_fence(); }
       TN_STAMP(0);
       constexpr bool MERGED = TWISTED && CAN_MERGE;
@@ -474,6 +494,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       constexpr bool MERGED = TWISTED && CAN_MERGE;
       TwRaw w0[ITERS][GROUP];
       enter(xa, xn, twisted_, tw_in, w0);                          // :82
+      publish_next();
       sched_fence();
       if constexpr (DEFER) emit_row(vprev, prev_row, zero);
       load_row(xb, b, row, zero);
@@ -510,8 +531,9 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     TN_STAMP(5);
     if (restage) { __syncthreads(); stage_table(om_fwd); }
   };
-  for (; row < batch; row += gridDim.x) {
-    const u32 next = row + gridDim.x;
+  while (row < batch) {
+    next = wave_uniform(lds_next[slot]);                           // published at least one workgroup barrier ago
+    if (sched && threadIdx.x == 0) got = atomicAdd(&sched[0], 1u); // the index after that: requested now, published by publish_next()
     const u32 zero = opaque_zero();                                // pins the column bases (scalar adds) inside the row loop
     const Tw* tw_in = opaque_sptr(psi_pow);
     const Tw* tw_out = opaque_sptr(psi_inv_ninv);
@@ -523,6 +545,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
       TwRaw w0[ITERS][GROUP];
       if (mode == CG_TWIST_FWD) {                                  // forward_ntt_bench: twist + cg_ntt
         enter(xa, xn, True(), tw_in, w0);
+        publish_next();
         sched_fence();
         load_row(xn, a, nrow, zero);
         first_trip(xa, om_fwd, tr, std::integral_constant<bool, CAN_MERGE>(), w0);
@@ -530,19 +553,25 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
         store_row(xa, row, K0(), zero, tw_out);
       } else {
         enter(xa, xn, False(), tw_in, w0);
+        publish_next();
         sched_fence();
         load_row(xn, a, nrow, zero);
         if (mode == CG_NTT_INV) { transform(xa, om_inv, false, nullptr); store_row(xa, row, K1(), zero, tw_out); }       // cg_intt: cg_ntt.py:68-75
         else { transform(xa, om_fwd, false, tr); store_row(xa, row, K0(), zero, tw_out); }
       }
     }
+    if (ntrips == 1) __syncthreads();                              // (a single trip has no barrier of its own between the slot's write and its read)
+    row = next; slot ^= 1u;
   }
   if constexpr (DEFER) { if (have_prev) emit_row(vprev, prev_row, 0u); }
+  // the last workgroup to run out of rows re-arms the counters for the next launch that uses this slot
+  if (sched && threadIdx.x == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1) { sched[0] = 0; sched[1] = 0; }
 #ifdef TN_CG_STAMPS
   if (trace && (mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL) && (threadIdx.x & 63) == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(trace) + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;
     for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
-    o[8] = st_bar; o[9] = __builtin_amdgcn_s_memtime() - st_begin; o[10] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o[11] = st_begin;      // [10]: the same interval on the constant 100 MHz clock
+    o[8] = st_bar; o[9] = __builtin_amdgcn_s_memtime() - st_begin; o[10] = __builtin_amdgcn_s_memrealtime() - st_rbegin;      // [10]: the same interval on the constant 100 MHz clock
+    o[11] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));   // where the wave ran
   }
 #endif
 }
@@ -571,7 +600,7 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
   const u32 tp = n / Sh::R;
   u32 threads = tp < 64 ? 64 : (tp > (u32)Sh::THREADS_MAX ? (u32)Sh::THREADS_MAX : tp);
   if ((tp + threads - 1) / threads > (u32)Sh::ITERS) return hipErrorInvalidValue;
-  const size_t lds_bytes = (size_t)(Sh::PINGPONG ? 2 : 1) * ((M::span(n) + 3u) & ~3u) * sizeof(E) + (size_t)(n / 2 + 1) * sizeof(Tw);
+  const size_t lds_bytes = (size_t)(Sh::PINGPONG ? 2 : 1) * ((M::span(n) + 3u) & ~3u) * sizeof(E) + (size_t)(n / 2 + 1) * sizeof(Tw) + 16;   // + the next-row slots
   auto kern = cg_kernel<E, GROUP, LAYOUT, AM, BIG, CTLOGN>;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {
@@ -588,9 +617,15 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
 #ifdef TN_CG_STAMPS
   if (!trace && (mode & 0xff) == CG_POLYMUL) trace = tn_cg_stamp_buffer((size_t)grid * (threads / 64) * 12 * sizeof(unsigned long long));
 #endif
+  // rows from the device-wide counter when every resident workgroup gets at least TN_CG_DYNAMIC_MIN rows (one counter pair per launch
+  // in flight: plan.h sched_acquire; no pair free, or the stream is being captured: fixed stride)
+  SchedSlot slot;
+  if (TN_CG_DYNAMIC_ROWS && batch >= (size_t)TN_CG_DYNAMIC_MIN * resident) slot = sched_acquire(p, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, pv.ar, logn, mode, pv.omega_pow, pv.omega_inv_pow, pv.psi_pow,
-                     pv.psi_inv_ninv, pv.psi_inv_pow, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch);
-  return hipGetLastError();
+                     pv.psi_inv_ninv, pv.psi_inv_pow, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch, slot.ptr);
+  const hipError_t le = hipGetLastError();
+  sched_release(p, slot, s, le == hipSuccess);
+  return le;
 }
 
 }  // namespace tn

@@ -36,4 +36,23 @@ for v in variants:
     # in-kernel clock: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz clock, both over the wave's lifetime
     clk = np.median(st[:, 9] / np.maximum(st[:, 10], 1)) * 100e6
     life = np.median(st[:, 10]) / 100e6
+    lt = np.sort(st[:, 10]) / 100e6 * 1e3
+    pct = lambda f: lt[min(len(lt) - 1, int(f * len(lt)))]
+    print(f"   wave lifetimes (ms): min {lt[0]:.3f}  10% {pct(.1):.3f}  50% {pct(.5):.3f}  90% {pct(.9):.3f}  99% {pct(.99):.3f}  max {lt[-1]:.3f}")
+    # where each wave ran: HW_ID (wave [3:0], simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID [3:0]
+    hw = st[:, 11] & 0xffffffff; xcc = (st[:, 11] >> 32) & 0xf
+    cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+    life = st[:, 10] / 100e6 * 1e3
+    ids, counts = np.unique(cu, return_counts=True)
+    print(f"   {len(ids)} distinct CUs ran waves; waves per CU: " + ", ".join(f"{c} waves on {int((counts == c).sum())} CUs" for c in np.unique(counts)))
+    for c in np.unique(counts):
+        sel = np.isin(cu, ids[counts == c])
+        print(f"   CUs with {c} waves: wave lifetime mean {life[sel].mean():.3f} ms (min {life[sel].min():.3f}, max {life[sel].max():.3f})")
+    print("   mean lifetime per XCD: " + "  ".join(f"{int(x)}: {life[xcc == x].mean():.3f}" for x in np.unique(xcc)))
+    simd = (hw >> 4) & 3
+    per = {}
+    for i in range(len(cu)): per.setdefault((int(cu[i]), int(simd[i])), []).append(life[i])
+    ns = np.array([len(v) for v in per.values()]); 
+    print("   waves per (CU, SIMD): " + ", ".join(f"{c}: {int((ns == c).sum())}" for c in np.unique(ns)) +
+          ";  mean lifetime by that count: " + ", ".join(f"{c}: {np.mean([np.mean(v) for v in per.values() if len(v) == c]):.3f}" for c in np.unique(ns)))
     print(f"   in-kernel clock {clk / 1e9:.3f} GHz (s_memtime / s_memrealtime over a wave's lifetime, median); a wave lives {life * 1e3:.3f} ms of the {ms:.3f} ms launch")
