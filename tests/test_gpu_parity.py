@@ -544,6 +544,56 @@ def test_signed_host_values_and_device_bit_patterns(eng, oracle):
     assert not np.array_equal(ref_values, ref_patterns)
 
 
+def test_constant_geometry_kernels_take_rows_from_the_counter_like_the_fused_ones(eng):
+    """The persistent constant-geometry kernels hand out rows through the same device counters (cg_kernel_impl.h: long launches;
+    fixed stride for short ones and under stream capture).  Every row of long and short launches, products and standalone
+    transforms, several streams at once and more back-to-back launches than the ring has slots must equal the fused kernel's rows
+    (a skipped or doubled row shows as a mismatch: the outputs start zeroed)."""
+    import torch
+    for tag, sizes in (("P4096_60", [9000, 4097, 300]), ("P256", [70000, 40001, 515])):
+        plan = plan_for(eng, tag)
+        ins = [(plan.fill_lcg(B, 20 * i + 1, 2), plan.fill_lcg(B, 20 * i + 2, 2)) for i, B in enumerate(sizes)]
+        ref = [plan.poly_mult(a, b, variant="fused") for a, b in ins]
+        ref_t = [plan.ntt_forward(a, variant="fused") for a, _ in ins]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in sizes]
+        for variant in ("cg8_padded", "cg4_swizzled", "cg"):
+            for rep in range(2):
+                outs = [torch.zeros_like(a) for a, _ in ins]; outs_t = [torch.zeros_like(a) for a, _ in ins]
+                torch.cuda.synchronize()
+                for (a, b), st, o, ot in zip(ins, streams, outs, outs_t):
+                    plan.poly_mult(a, b, out=o, variant=variant, stream=st)
+                    plan.ntt_forward(a, variant=variant, out=ot, stream=st)
+                torch.cuda.synchronize()
+                for i in range(len(sizes)):
+                    assert torch.equal(outs[i], ref[i]), (tag, variant, rep, i)
+                    assert torch.equal(outs_t[i], ref_t[i]), (tag, variant, rep, i)
+        a, b = ins[0]
+        c = torch.zeros_like(a)
+        for _ in range(1100 if tag == "P256" else 40):     # the ring (1,024 pairs) wraps; every pair re-arms itself
+            plan.poly_mult(a, b, out=c, variant="cg8_padded")
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref[0]), tag
+    # captured launches run the fixed stride (no counter pair is baked into a graph node)
+    plan = plan_for(eng, "P4096_60")
+    a, b = plan.fill_lcg(6144, 1, 2), plan.fill_lcg(6144, 2, 2)
+    ref = plan.poly_mult(a, b)
+    s1 = torch.cuda.Stream(); c = torch.zeros_like(a)
+    with torch.cuda.stream(s1):
+        plan.poly_mult(a, b, out=c, variant="cg8_padded", stream=s1)
+    s1.synchronize()
+    g = torch.cuda.CUDAGraph(); c.zero_(); torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s1):
+        plan.poly_mult(a, b, out=c, variant="cg8_padded", stream=s1)
+    for rep in range(3):
+        c.zero_(); torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            g.replay()
+        plan.poly_mult(a, b, variant="cg8_padded")          # a live, dynamically scheduled launch beside the replay
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref), rep
+
+
 def test_graph_capture_uses_the_fixed_stride_and_replays_beside_live_launches(eng):
     """A launch captured into a hipGraph must not take a slot of the dynamic row scheduler (the slot pointer would be baked into
     the kernel node while the ring keeps advancing, and a later replay could share a counter pair with a live launch: rows

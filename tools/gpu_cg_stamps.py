@@ -44,15 +44,15 @@ for v in variants:
     cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
     life = st[:, 10] / 100e6 * 1e3
     ids, counts = np.unique(cu, return_counts=True)
-    print(f"   {len(ids)} distinct CUs ran waves; waves per CU: " + ", ".join(f"{c} waves on {int((counts == c).sum())} CUs" for c in np.unique(counts)))
-    for c in np.unique(counts):
-        sel = np.isin(cu, ids[counts == c])
-        print(f"   CUs with {c} waves: wave lifetime mean {life[sel].mean():.3f} ms (min {life[sel].min():.3f}, max {life[sel].max():.3f})")
+    print(f"   {len(ids)} distinct CUs ran waves; waves per CU: " + ", ".join(f"{k} waves on {int((counts == k).sum())} CUs" for k in np.unique(counts)))
+    for k in np.unique(counts):
+        sel = np.isin(cu, ids[counts == k])
+        print(f"   CUs with {k} waves: wave lifetime mean {life[sel].mean():.3f} ms (min {life[sel].min():.3f}, max {life[sel].max():.3f})")
     print("   mean lifetime per XCD: " + "  ".join(f"{int(x)}: {life[xcc == x].mean():.3f}" for x in np.unique(xcc)))
     simd = (hw >> 4) & 3
     per = {}
     for i in range(len(cu)): per.setdefault((int(cu[i]), int(simd[i])), []).append(life[i])
     ns = np.array([len(v) for v in per.values()]); 
-    print("   waves per (CU, SIMD): " + ", ".join(f"{c}: {int((ns == c).sum())}" for c in np.unique(ns)) +
-          ";  mean lifetime by that count: " + ", ".join(f"{c}: {np.mean([np.mean(v) for v in per.values() if len(v) == c]):.3f}" for c in np.unique(ns)))
-    print(f"   in-kernel clock {clk / 1e9:.3f} GHz (s_memtime / s_memrealtime over a wave's lifetime, median); a wave lives {life * 1e3:.3f} ms of the {ms:.3f} ms launch")
+    print("   waves per (CU, SIMD): " + ", ".join(f"{k}: {int((ns == k).sum())}" for k in np.unique(ns)) +
+          ";  mean lifetime by that count: " + ", ".join(f"{k}: {np.mean([np.mean(v) for v in per.values() if len(v) == k]):.3f}" for k in np.unique(ns)))
+    print(f"   in-kernel clock {clk / 1e9:.3f} GHz (s_memtime / s_memrealtime over a wave's lifetime, median); a wave lives {np.median(life):.3f} ms (median) of the {ms:.3f} ms launch")
