@@ -1,6 +1,7 @@
 """CPU stepping of the product kernels' per-thread code (tests/emu) against golden vectors and the
 oracle: validates index maps, LDS layouts, table semantics, lazy-reduction bounds and the modular
 primitives of tiny_ntt_amd/csrc/*.h without a GPU."""
+import os
 import random
 
 import numpy as np
@@ -339,3 +340,20 @@ def test_n8192_60bit_emulation_and_oracle_match_reference_golden(emu, oracle):
     xm = np.zeros(n, dtype=np.uint64); xm[n - 1] = 1
     x1 = np.zeros(n, dtype=np.uint64); x1[1] = 1
     assert np.array_equal(emu.fused(n, q, psi, xm[None], x1[None])[0], g["wrap_c"])
+
+
+def test_kernel_bodies_under_address_and_ub_sanitizers():
+    """GPU sanitizers are not available on the pool: the kernels' per-thread code (the product's own headers, stepped on the CPU by
+    tests/emu) runs under AddressSanitizer + UndefinedBehaviorSanitizer instead - every LDS image / table index, every shift count
+    of fused_core.h, cg_core.h and plan_tables.h for n = 16 ... 4096, both lane widths, every GROUP x layout x arithmetic of the
+    constant-geometry trips, fused products and transforms.  The driver also cross-checks every result (tests/emu/sanitize_driver.cpp)."""
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    b = subprocess.run(["make", "-C", d, "sanitize"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert b.returncode == 0, b.stdout[-2000:]
+    r = subprocess.run([os.path.join(d, "_build", "sanitize_driver")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    m = __import__("re").search(r"(\d+) checks, 0 failures", r.stdout)
+    assert m and int(m.group(1)) > 1500, r.stdout
