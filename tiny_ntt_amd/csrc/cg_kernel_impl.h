@@ -21,6 +21,9 @@
 #ifndef TN_CG_DYNAMIC_MIN
 #define TN_CG_DYNAMIC_MIN 8
 #endif
+#ifndef TN_CG_CHUNK_BYTES
+#define TN_CG_CHUNK_BYTES 32768  // bytes of one operand handed out per atomicAdd (as TN_SCHED_CHUNK_BYTES of the fused kernels)
+#endif
 #ifndef TN_CG_NT_STREAM
 #define TN_CG_NT_STREAM 1        // 1: non-temporal loads/stores for the streamed operands (keeps L2 for the tables)
 #endif
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__((CgShape<E, GROUP, BIG, CTLOGN>::THREADS_MAX),
 cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>::type* __restrict__ om_fwd,
           const typename TwOf<E>::type* __restrict__ om_inv, const typename TwOf<E>::type* __restrict__ psi_pow,
           const typename TwOf<E>::type* __restrict__ psi_inv_ninv, const typename TwOf<E>::type* __restrict__ psi_inv_pow,
-          const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* __restrict__ trace, u32 batch, u32* sched) {
+          const E* __restrict__ a, const E* __restrict__ b, E* __restrict__ out, E* __restrict__ trace, u32 batch, u32* sched, u32 chunk) {
   // (the tables are separate __restrict__ arguments so that wave-uniform twiddle loads become scalar loads: see polymul_fused_kernel)
   typedef CgGeom<GROUP> Ge;
   typedef CgMap<E, GROUP, LAYOUT> M;
@@ -407,7 +410,19 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   // The index travels through LDS one row ahead of its use: while row k runs, every thread reads the index of row k+1 from one
   // slot (written during row k-1) and thread 0 requests the index of row k+2 and writes it to the other slot; the workgroup
   // barriers inside every row order each slot's write before its read and its read before the next write.
-  if (threadIdx.x == 0) lds_next[0] = sched ? gridDim.x + atomicAdd(&sched[0], 1u) : blockIdx.x + gridDim.x;
+  // Rows are handed out in chunks of `chunk` consecutive rows (>= 32 KiB of one operand: one atomic per short row would make the one
+  // counter address the bottleneck, as measured on the fused kernels); chunk blockIdx.x first.  The publisher's cursor: how many rows
+  // of the current chunk are out and - fixed stride - which chunk that is (workgroup-uniform; the last published row is `next`).
+  u32 pub_taken = 1, chunk_id = blockIdx.x, got = 0;
+  bool need = pub_taken == chunk;                                  // the next row to publish opens a new chunk
+  if (need && sched && threadIdx.x == 0) got = atomicAdd(&sched[0], 1u);
+  auto publish = [&](u32 slot_, u32 last) TN_INL {                 // last: the row published before this one (workgroup-uniform)
+    u32 v = last + 1u;
+    if (need) { chunk_id += gridDim.x; v = (sched ? gridDim.x + got : chunk_id) * chunk; pub_taken = 1; }
+    else pub_taken += 1;
+    if (threadIdx.x == 0) lds_next[slot_] = v;                     // (only thread 0 holds the atomic's answer)
+  };
+  publish(0u, blockIdx.x * chunk);
   stage_table(mode == CG_NTT_INV ? om_inv : om_fwd);
   __syncthreads();
 
@@ -429,7 +444,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
 #endif
   constexpr bool AHEAD = TN_CG_AHEAD && GROUP == 8;
   E xm[AHEAD ? ITERS : 1][R];
-  u32 row = blockIdx.x;
+  u32 row = blockIdx.x * chunk;
   if (row < batch) {
     load_row(xn, a, row, 0u);
     if constexpr (AHEAD) { if (mode == CG_POLYMUL || mode == CG_CYCLIC_POLYMUL) load_row(xm, b, row, 0u); }
@@ -453,10 +468,10 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
 #pragma unroll
       for (int e = 0; e < R; ++e) vprev[it][e] = 0;
   }
-  u32 slot = 0, next = 0, got = 0;                                 // slot: which of the two LDS slots holds the next row's index
+  u32 slot = 0, next = 0;                                          // slot: which of the two LDS slots holds the next row's index
   // called once per row, after the row's first table fetch has been consumed (the atomic's latency hides behind it): thread 0
   // publishes the index of the row after `next`
-  auto publish_next = [&]() TN_INL { if (threadIdx.x == 0) lds_next[slot ^ 1u] = sched ? gridDim.x + got : next + gridDim.x; };
+  auto publish_next = [&]() TN_INL { publish(slot ^ 1u, next); };
   auto product_row = [&](auto twisted_, u32 nrow, u32 zero, const Tw* tw_in, const Tw* tw_out) TN_INL {
     constexpr bool TWISTED = decltype(twisted_)::value;
     E xb[ITERS][R];
@@ -533,7 +548,8 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   };
   while (row < batch) {
     next = wave_uniform(lds_next[slot]);                           // published at least one workgroup barrier ago
-    if (sched && threadIdx.x == 0) got = atomicAdd(&sched[0], 1u); // the index after that: requested now, published by publish_next()
+    need = pub_taken == chunk;                                     // the row after that opens a new chunk: requested now, published by publish_next()
+    if (need && sched && threadIdx.x == 0) got = atomicAdd(&sched[0], 1u);
     const u32 zero = opaque_zero();                                // pins the column bases (scalar adds) inside the row loop
     const Tw* tw_in = opaque_sptr(psi_pow);
     const Tw* tw_out = opaque_sptr(psi_inv_ninv);
@@ -611,7 +627,14 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
   hipError_t qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)threads, lds_bytes);
   if (qe != hipSuccess || per_cu < 1) per_cu = 1;
   const size_t resident = (size_t)per_cu * (size_t)p->num_cus;
-  const u32 grid = (u32)(batch < resident ? batch : resident);
+  // dynamic hand-out in chunks of >= TN_SCHED_CHUNK_BYTES of one operand when every resident workgroup gets at least TN_CG_DYNAMIC_MIN
+  // chunks; otherwise single rows at a fixed stride
+  size_t chunk = 1;
+  if (TN_CG_DYNAMIC_ROWS) { chunk = (size_t)TN_CG_CHUNK_BYTES / ((size_t)n * sizeof(E)); if (chunk < 1) chunk = 1; }
+  const bool dynamic = TN_CG_DYNAMIC_ROWS && batch >= (size_t)TN_CG_DYNAMIC_MIN * resident * chunk;
+  if (!dynamic) chunk = 1;
+  const size_t chunks = (batch + chunk - 1) / chunk;
+  const u32 grid = (u32)(chunks < resident ? chunks : resident);
   const PlanView<E> pv = make_view<E>(p);
   if (p->general) mode |= CG_FLAG_RESTAGE;
 #ifdef TN_CG_STAMPS
@@ -620,9 +643,10 @@ static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const v
   // rows from the device-wide counter when every resident workgroup gets at least TN_CG_DYNAMIC_MIN rows (one counter pair per launch
   // in flight: plan.h sched_acquire; no pair free, or the stream is being captured: fixed stride)
   SchedSlot slot;
-  if (TN_CG_DYNAMIC_ROWS && batch >= (size_t)TN_CG_DYNAMIC_MIN * resident) slot = sched_acquire(p, s);
+  if (dynamic) slot = sched_acquire(p, s);
+  if (!slot.ptr) chunk = 1;                                       // (no pair free / stream capture: fixed stride of single rows; the grid stays)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, pv.ar, logn, mode, pv.omega_pow, pv.omega_inv_pow, pv.psi_pow,
-                     pv.psi_inv_ninv, pv.psi_inv_pow, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch, slot.ptr);
+                     pv.psi_inv_ninv, pv.psi_inv_pow, (const E*)a, (const E*)b, (E*)out, (E*)trace, (u32)batch, slot.ptr, (u32)chunk);
   const hipError_t le = hipGetLastError();
   sched_release(p, slot, s, le == hipSuccess);
   return le;
