@@ -1,6 +1,6 @@
 // cg_kernel_impl.h — the constant-geometry kernel (K1-K5/K7 of SURVEY.md §2; BASELINE config 5) and its launcher template.
 // Included by the cg_part*.hip translation units, each of which instantiates one slice of
-// (lane width, arithmetic, lane grouping, LDS layout); cg_launch.hip picks the slice for a plan.
+// (lane width, arithmetic, lane grouping, LDS layout); launch_cg() in kernels.hip picks the slice for a plan.
 //
 // The reference's dataflow (cg_ntt.py:49-64, cg_ntt_8butterfly.py:61-97) run as TRIPS of log2(2 GROUP) stages in registers
 // (cg_core.h): GROUP = 8 -> four stages per LDS round trip, three trips at n = 4096.  Per workgroup: ONE image of the
@@ -9,6 +9,7 @@
 // The inverse transform of a product reads the same LDS table backwards (omega^-j = -omega^(n/2-j): the butterfly's two
 // outputs change places), so one table serves both directions.
 // Per product: read a, read b, write c in HBM; 6 LDS transposes (two per transform), 12 workgroup barriers at GROUP = 8.
+// Persistent workgroups; rows handed out by a device-wide counter (plan.h: sched_acquire) or at a fixed stride.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "plan.h"
@@ -431,7 +432,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
   typedef std::integral_constant<int, 0> K0;
   typedef std::integral_constant<int, 1> K1;
   typedef std::integral_constant<int, 2> K2;
-  // Persistent workgroup over rows blockIdx.x, + gridDim.x, ...; the next row's first operand is requested from HBM
+  // Persistent workgroup over the rows the hand-out below gives it; the next row's first operand is requested from HBM
   // before the last transform of the current row and consumed at the top of the next iteration.  One body per mode,
   // each with its switches compiled in (a run-time switch inside a body keeps both sides' registers alive).
   E xa[ITERS][R], xn[ITERS][R];
@@ -603,8 +604,8 @@ inline void* tn_cg_stamp_buffer(size_t bytes) {
 }
 #endif
 
-// Launch one slice.  Returns hipErrorInvalidValue for shapes the instantiation cannot run (the dispatcher in cg_launch.hip
-// only asks for valid ones).
+// Launch one slice.  Returns hipErrorInvalidValue for shapes the instantiation cannot run (the dispatcher, launch_cg() in
+// kernels.hip, only asks for valid ones).
 template <typename E, int GROUP, int LAYOUT, int AM, bool BIG, int CTLOGN>
 static hipError_t launch_cg_t(const tn_plan* p, int mode, const void* a, const void* b, void* out, void* trace, size_t batch,
                               hipStream_t s) {

@@ -11,4 +11,4 @@ if [ -f tiny_ntt_amd/lib/libtinyntt_stamps.so ]; then TINYNTT_LIB=$R/tiny_ntt_am
 if [ -f tiny_ntt_amd/lib/libtinyntt_fstamps.so ]; then TINYNTT_LIB=$R/tiny_ntt_amd/lib/libtinyntt_fstamps.so tos 200 python tools/gpu_fused_clock.py > gpurun_out/$TAG/fused_clock.txt 2>&1; grep -v amdgpu gpurun_out/$TAG/fused_clock.txt; fi
 for v in cg8_padded cg4_padded cg8 cg; do echo "#### $v"; SPIN_VARIANT=$v sub tools/gpu_clock_probe.sh base; done > gpurun_out/$TAG/cg_clock.log 2>&1; grep -c sclk gpurun_out/$TAG/cg_clock.log
 tos 200 python tools/gpu_latency.py > gpurun_out/$TAG/latency.txt 2>&1
-for seed in 5 6; do tos 330 python tests/dev/gpu_fuzz.py $seed 300 > gpurun_out/$TAG/fuzz_$seed.txt 2>&1; tail -1 gpurun_out/$TAG/fuzz_$seed.txt; done
+for seed in ${FUZZ_SEEDS:-5 6}; do tos 330 python tests/dev/gpu_fuzz.py $seed 300 > gpurun_out/$TAG/fuzz_$seed.txt 2>&1; tail -1 gpurun_out/$TAG/fuzz_$seed.txt; done
