@@ -574,6 +574,20 @@ def test_constant_geometry_kernels_take_rows_from_the_counter_like_the_fused_one
             plan.poly_mult(a, b, out=c, variant="cg8_padded")
         torch.cuda.synchronize()
         assert torch.equal(c, ref[0]), tag
+    # rows shorter than 32 KiB are handed out in chunks of several rows per atomic: n = 2048 / 60-bit -> 2 rows, n = 1024 / 24-bit -> 8;
+    # an odd batch leaves the last chunk partly past the end
+    from tiny_ntt_amd import numtheory
+    for n, q, rows in ((2048, 1152921504606830593, 20001), (1024, 8380417, 200003)):
+        plan = eng.get_plan(n, q, numtheory.primitive_2n_root(n, q))
+        a, b = plan.fill_lcg(rows, 3, 2), plan.fill_lcg(rows, 4, 2)
+        ref = plan.poly_mult(a, b, variant="fused")
+        for variant in ("cg8_padded", "cg4_padded", "cg"):
+            for rep in range(2):
+                c = torch.zeros_like(a)
+                plan.poly_mult(a, b, out=c, variant=variant)
+                torch.cuda.synchronize()
+                assert torch.equal(c, ref), (n, variant, rep)
+        del a, b, c, ref
     # captured launches run the fixed stride (no counter pair is baked into a graph node)
     plan = plan_for(eng, "P4096_60")
     a, b = plan.fill_lcg(6144, 1, 2), plan.fill_lcg(6144, 2, 2)
