@@ -49,6 +49,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SPINUP = 40                             # untimed launches before the W warm-up steps (setup: the shader clock settles ~0.1 s after idle); on the line
+SPINUP_SECONDS = 0.15                   # ... and at least this long: 40 launches of a short workload (cfg2: 23 us each) end long before the clock has
+                                        # settled (measured: 23.5-24.5 us per step after 1 ms of launches, 20.4 us after 45 ms, profiles/r3_cfg2_short_launch_ab.txt)
 
 # parameter sets: SURVEY.md §8 table; checksums: what the reference benchmark prints for make_poly(1) x make_poly(2)
 CONFIGS = {
@@ -362,8 +364,12 @@ def main():
     checked, first_sum = verify(plan, a, b, c, first_row, cfg)
     # device spin-up (part of setup, like plan creation and data generation): after idle the first ~0.1 s of launches run
     # below the steady shader clock, whatever W the caller asks for
-    for _ in range(SPINUP):
-        plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
+    spin_launches, t_spin = 0, time.perf_counter()
+    while spin_launches < SPINUP or time.perf_counter() - t_spin < SPINUP_SECONDS:
+        for _ in range(32):
+            plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
+        spin_launches += 32
+        plan.synchronize()
     for _ in range(max(args.warmup, 0)):                      # the W untimed warm-up steps of the contract
         plan.poly_mult(a, b, variant=args.variant, out=c, stream=S)
     plan.synchronize()
@@ -509,7 +515,7 @@ def main():
             "strong_scaling_n1_point": curve,
             "per_rank": {"rows": [int(r[0]) for r in per_rank], "kernel_ms": [round(r[1], 4) for r in per_rank],
                          "ms_per_step": [round(r[2], 4) for r in per_rank]},
-            "spinup_launches": SPINUP,
+            "spinup_launches": spin_launches,
         }
         if traffic_note:
             line["roofline"]["traffic_note"] = traffic_note
