@@ -1,8 +1,10 @@
 """Developer tool: kernel time of every BASELINE configuration that runs on one GPU (parity is covered by tests)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import time
 import torch
 from tiny_ntt_amd import engine
+SPIN_S = 0.15        # launches before any timing: the shader clock settles ~0.1 s after idle (short launches would otherwise be timed on the ramp)
 CFG = [("cfg2 n=1024 24-bit batch=4096", 1024, 8380417, 5548360, 4096, 4),
        ("n=1024 24-bit batch=262144", 1024, 8380417, 5548360, 262144, 4),
        ("n=4096 24-bit batch=65536", 4096, 8380417, 283817, 65536, 4),
@@ -12,8 +14,11 @@ CFG = [("cfg2 n=1024 24-bit batch=4096", 1024, 8380417, 5548360, 4096, 4),
 for name, n, q, psi, B, w in CFG:
     plan = engine.Plan(n, q, psi)
     a = plan.fill_lcg(B, 1, 2); b = plan.fill_lcg(B, 2, 2); c = torch.empty_like(a)
-    plan.time_poly_mult(a, b, c, 3)
-    ms = min(plan.time_poly_mult(a, b, c, 10) for _ in range(3))
+    t0 = time.perf_counter(); est = plan.time_poly_mult(a, b, c, 3)
+    while time.perf_counter() - t0 < SPIN_S:
+        plan.time_poly_mult(a, b, c, 32)
+    iters = max(10, min(2000, int(20.0 / est)))                       # >= 20 ms per timing
+    ms = min(plan.time_poly_mult(a, b, c, iters) for _ in range(3))
     print(f"{name:62s} {ms:8.3f} ms  {B/ms*1e3/1e6:8.2f} M polymul/s  {B*3*n*w/ms/1e6:7.0f} GB/s  frac {B*3*n*w/ms/1e6/8000:.3f}  lazy={plan.is_lazy}", flush=True)
     del a, b, c; plan.close(); torch.cuda.empty_cache()
 
@@ -26,11 +31,15 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 for name, fn in (("cg_ntt fused", lambda: plan.ntt_forward(x, variant="fused", out=y)), ("cg_intt fused", lambda: plan.ntt_inverse(x, variant="fused", out=y)),
                  ("twist+ntt fused", lambda: plan.twisted_ntt_forward(x, variant="fused", out=y)), ("cg_ntt cg", lambda: plan.ntt_forward(x[:8192], variant="cg", out=y[:8192]))):
     fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < SPIN_S:
+        for _ in range(8): fn()
+        torch.cuda.synchronize()
     ev0.record()
-    for _ in range(5): fn()
+    for _ in range(40): fn()
     ev1.record(); torch.cuda.synchronize()
     rows = 8192 if name.endswith(" cg") else B
-    ms = ev0.elapsed_time(ev1) / 5
+    ms = ev0.elapsed_time(ev1) / 40
     print(f"{name:18s} {ms:8.3f} ms  {rows/ms*1e3/1e6:8.2f} M NTT/s  {rows*2*n*8/ms/1e6:7.0f} GB/s (2nw bytes)", flush=True)
 
 # measured HBM copy bandwidth on this box ("also record measured copy bandwidth"): 2 GiB device-to-device
