@@ -31,7 +31,8 @@ def test_single_gpu_line_small_workload():
     assert p["bit_exact"] is True and p["first_row_checksum_device"] == p["reference_row0_checksum"] == 2710933653778106521
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["algorithmic_bytes_per_launch"] == 2048 * 98304 and 0 < r["frac"] < 1
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    # (kernel_ms is printed with four decimals: at 0.08 ms per launch that alone is 0.06 % of the quotient)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.002 * r["achieved"]
     assert j["config"]["lib_build_id"] not in ("", "unknown")
     assert j["per_rank"]["rows"] == [2048] and set(j["latency"]["device_resident_us"]) == {"1", "16", "256"} and j["latency"]["host_buffer_us"]["1"] > 0
     assert j["strong_scaling_n1_point"] is None          # only with --strong-point
@@ -57,4 +58,4 @@ def test_two_ranks_without_launcher_strong_split_over_gloo():
     assert j["parity"]["bit_exact"] is True
     # a straggler would show in the per-rank lists; the N = 1 blocks stay off an N > 1 line
     assert j["per_rank"]["rows"] == [1500, 1500] and len(j["per_rank"]["kernel_ms"]) == 2 and min(j["per_rank"]["kernel_ms"]) > 0
-    assert j["latency"] is None and j["strong_scaling_n1_point"] is None and j["spinup_launches"] == 40
+    assert j["latency"] is None and j["strong_scaling_n1_point"] is None and j["spinup_launches"] >= 40          # at least 40 launches and 0.15 s of them (bench.py: SPINUP, SPINUP_SECONDS)
