@@ -482,7 +482,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": sp["scaling"],
             "vs_baseline": None,
@@ -508,13 +508,13 @@ def main():
                        "bit_exact": bool(parity_ok and (first_row != 0 or first_sum == cfg["checksum_row0"]))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": plan.kernel_name(args.variant), "kernel_ms": round(kernel_ms, 4),
+                         "kernel": plan.kernel_name(args.variant), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": max_rows * bytes_per_product},
             "cpu_baseline": base,
             "latency": latency,
             "strong_scaling_n1_point": curve,
-            "per_rank": {"rows": [int(r[0]) for r in per_rank], "kernel_ms": [round(r[1], 4) for r in per_rank],
-                         "ms_per_step": [round(r[2], 4) for r in per_rank]},
+            "per_rank": {"rows": [int(r[0]) for r in per_rank], "kernel_ms": [round(r[1], 5) for r in per_rank],
+                         "ms_per_step": [round(r[2], 5) for r in per_rank]},
             "spinup_launches": spin_launches,
         }
         if traffic_note:
