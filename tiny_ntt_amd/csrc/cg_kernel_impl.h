@@ -404,7 +404,7 @@ cg_kernel(const Arith<E> ar, u32 logn_rt, int mode_flags, const typename TwOf<E>
     emit_row(v, row, zero);
   };
 
-  // Row hand-out.  sched != nullptr: rows come from a device-wide counter (one atomicAdd per row, by thread 0), as in the fused
+  // Row hand-out.  sched != nullptr: rows come from a device-wide counter (one atomicAdd per chunk of rows, by thread 0), as in the fused
   // kernels: the two workgroups of a CU do not run at the same speed (the SIMD's issue arbitration favours the older wave: with
   // equal fixed shares one workgroup finished after 1.83 ms and its neighbour ran the last 0.9 ms alone, profiles/r3_cg_stamps.txt),
   // so the faster one simply takes more rows and the launch ends when the work does.  sched == nullptr: fixed stride gridDim.x.
